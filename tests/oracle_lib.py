@@ -1,0 +1,198 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class Fe(C.Structure):
+    _fields_ = [("l", C.c_uint64 * 4)]
+
+    @classmethod
+    def from_int(cls, v):
+        f = cls()
+        for i in range(4):
+            f.l[i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+        return f
+
+    def to_int(self):
+        return sum(int(self.l[i]) << (64 * i) for i in range(4))
+
+
+class Pt(C.Structure):
+    _fields_ = [("x", Fe), ("y", Fe)]
+
+    @classmethod
+    def from_ints(cls, x, y):
+        p = cls()
+        p.x = Fe.from_int(x)
+        p.y = Fe.from_int(y)
+        return p
+
+    def to_ints(self):
+        return (self.x.to_int(), self.y.to_int())
+
+
+class Hit(C.Structure):
+    _fields_ = [("code", C.c_uint32), ("idx", C.c_uint32)]
+
+
+class Job(C.Structure):
+    _fields_ = [("t", C.c_uint32), ("b", C.c_uint32), ("p", C.c_uint32), ("w", C.c_uint64),
+                ("htsz", C.c_uint32), ("maxnonce", C.c_uint64), ("addpubg", Pt), ("center_big", Fe),
+                ("center", Pt), ("prkaddbig", Fe), ("pubaddbig", Pt), ("priv_big", Fe),
+                ("pubkey_big", Pt), ("realpub", Pt), ("findpub", Pt), ("glob_key", Fe), ("glob_pub", Pt)]
+
+
+def build():
+    """(Re)build liboracle.so with gcc if it is missing or older than its sources."""
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("curve64_ref.c", "bsgs_ref.c", "curve64_ref.h", "bsgs_ref.h")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        pfe, ppt = C.POINTER(Fe), C.POINTER(Pt)
+        u8p = C.c_void_p
+        sig = {
+            "o_sethex32": (C.c_int, [pfe, C.c_char_p]),
+            "o_gethex32": (None, [C.c_char_p, pfe]),
+            "o_addX64": (C.c_uint64, [pfe, pfe, pfe]),
+            "o_subX64": (C.c_uint64, [pfe, pfe, pfe]),
+            "o_andX64": (None, [pfe, pfe, pfe]),
+            "o_addModX64": (None, [pfe, pfe, pfe, pfe]),
+            "o_subModX64": (None, [pfe, pfe, pfe, pfe]),
+            "o_mulModX64": (None, [pfe, pfe, pfe]),
+            "o_squareModX64": (None, [pfe, pfe]),
+            "o_modInvX64": (None, [pfe, pfe, pfe]),
+            "o_DBLTX64": (None, [ppt, ppt]),
+            "o_ADDPTX64": (None, [ppt, ppt, ppt]),
+            "o_PTMULX64": (None, [ppt, ppt, pfe]),
+            "o_YfromX64": (None, [pfe, pfe]),
+            "o_fillarrayN": (None, [u8p, C.c_size_t, ppt]),
+            "o_build_baby_tables": (C.c_int, [C.c_uint64, C.c_uint32, u8p, u8p]),
+            "o_pack_tables_from_keys": (C.c_int, [u8p, C.c_uint64, C.c_uint32, u8p, u8p]),
+            "o_ht_filename": (None, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int]),
+            "o_g2_filename": (None, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]),
+            "o_htgpu_probe": (C.c_int, [u8p, C.c_uint64, C.c_uint64]),
+            "o_htcpu_lookup": (C.c_int, [u8p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.c_int]),
+            "o_addpubg": (None, [ppt, C.c_uint64]),
+            "o_build_g2": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, u8p, u8p]),
+            "o_g2_unpack": (None, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]),
+            "o_tile_ref": (C.c_uint64, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint64,
+                                        C.c_uint32, C.POINTER(Hit), C.c_uint64]),
+            "o_tile_ref_slice": (C.c_uint64, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint64,
+                                              C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Hit), C.c_uint64]),
+            "o_tile_xs": (C.c_int, [ppt, ppt, C.c_uint32, pfe, pfe, pfe]),
+            "o_job_init": (C.c_int, [C.POINTER(Job), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
+                                     C.c_uint32, pfe, ppt, pfe]),
+            "o_getjob": (None, [C.POINTER(Job), pfe, ppt]),
+            "o_resolve_hit": (C.c_int, [C.POINTER(Job), u8p, C.c_uint64, C.c_uint32, C.c_uint32, pfe, ppt, pfe]),
+            "o_parse_pubkey": (C.c_int, [ppt, C.c_char_p]),
+            "o_compress_pub": (None, [C.c_char_p, ppt]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+# ---- convenience wrappers (ints in, ints out) ---------------------------------------------
+P_INT = 2**256 - 2**32 - 977
+N_INT = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+GX_INT = 0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798
+GY_INT = 0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8
+
+
+def fe_op(name, *ints, mod=None):
+    L = lib()
+    r = Fe()
+    args = [C.byref(Fe.from_int(v)) for v in ints]
+    if mod is not None:
+        args.append(C.byref(Fe.from_int(mod)))
+    getattr(L, name)(C.byref(r), *args)
+    return r.to_int()
+
+
+def pt_mul(k, pt=(GX_INT, GY_INT)):
+    r = Pt()
+    lib().o_PTMULX64(C.byref(r), C.byref(Pt.from_ints(*pt)), C.byref(Fe.from_int(k)))
+    return r.to_ints()
+
+
+def pt_add(a, b):
+    r = Pt()
+    lib().o_ADDPTX64(C.byref(r), C.byref(Pt.from_ints(*a)), C.byref(Pt.from_ints(*b)))
+    return r.to_ints()
+
+
+def pt_neg(a):
+    return (a[0], (-a[1]) % P_INT)
+
+
+def build_baby_tables(w, htsz):
+    items = 1 << htsz
+    gpu = C.create_string_buffer(4 * (items + 1) + 4 * w)
+    cpu = C.create_string_buffer(4 * (items + 1) + 8 * w)
+    rc = lib().o_build_baby_tables(w, htsz, C.cast(gpu, C.c_void_p), C.cast(cpu, C.c_void_p))
+    assert rc == 0
+    return gpu.raw, cpu.raw
+
+
+def pack_tables_from_keys(keys, htsz):
+    import numpy as np
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    w = len(keys)
+    items = 1 << htsz
+    gpu = C.create_string_buffer(4 * (items + 1) + 4 * w)
+    cpu = C.create_string_buffer(4 * (items + 1) + 8 * w)
+    rc = lib().o_pack_tables_from_keys(keys.ctypes.data_as(C.c_void_p), w, htsz,
+                                       C.cast(gpu, C.c_void_p), C.cast(cpu, C.c_void_p))
+    assert rc == 0
+    return gpu.raw, cpu.raw
+
+
+def build_g2(t, b, p, w):
+    maxnonce = t * b * p
+    packed = C.create_string_buffer(64 * maxnonce)
+    rc = lib().o_build_g2(t, b, p, w, C.cast(packed, C.c_void_p), None)
+    assert rc == 0
+    return packed.raw
+
+
+def g2_unpack(packed, t, b, p, i):
+    r = Pt()
+    buf = C.create_string_buffer(packed, len(packed)) if isinstance(packed, bytes) else packed
+    lib().o_g2_unpack(C.byref(r), C.cast(buf, C.c_void_p), t, b, p, i)
+    return r.to_ints()
+
+
+def tile_ref(P, g2, t, b, p, htgpu, htsz, flags=0, max_hits=4096):
+    hits = (Hit * max_hits)()
+    g2b = C.create_string_buffer(g2, len(g2)) if isinstance(g2, bytes) else g2
+    htb = C.create_string_buffer(htgpu, len(htgpu)) if isinstance(htgpu, bytes) else htgpu
+    n = lib().o_tile_ref(C.byref(Pt.from_ints(*P)), C.cast(g2b, C.c_void_p), t, b, p,
+                         C.cast(htb, C.c_void_p), 1 << htsz, flags, hits, max_hits)
+    return [(hits[i].code, hits[i].idx) for i in range(min(n, max_hits))], n
+
+
+def tile_xs(P, Gpt, flags=0):
+    xm, xp, xd = Fe(), Fe(), Fe()
+    eq = lib().o_tile_xs(C.byref(Pt.from_ints(*P)), C.byref(Pt.from_ints(*Gpt)), flags,
+                         C.byref(xm), C.byref(xp), C.byref(xd))
+    return eq, xm.to_int(), xp.to_int(), xd.to_int()
