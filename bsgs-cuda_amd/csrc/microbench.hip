@@ -1,0 +1,244 @@
+// microbench.hip -- roofline denominators for the giant-step kernel on MI355X (gfx950).
+//   (1) instruction issue rates that bound 256-bit modular multiplication:
+//       v_mad_u64_u32, v_mul_lo/hi_u32, v_add_co/v_addc carry chain, v_fma_f64, v_mad_u32_u24
+//   (2) random-read bandwidth of HBM at a given footprint and granule (GUPS style): the
+//       denominator SURVEY.md 8(d) asks for (neither guide gives one).
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 microbench.hip -o microbench
+// Run  : ./microbench [footprint_MiB ...]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef uint32_t u32; typedef uint64_t u64;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- instruction rates
+template <int OP>
+__global__ void __launch_bounds__(256) rate_kernel(u32 *out, int iters, u32 seed)
+{
+    u32 t = threadIdx.x + blockIdx.x * blockDim.x;
+    u32 a = seed * 2654435761u + t, b = a ^ 0x9E3779B9u;
+    u64 acc0 = a, acc1 = b, acc2 = a + 7, acc3 = b + 9;
+    u32 x0 = a, x1 = b, x2 = a + 3, x3 = b + 5;
+    double d0 = (double)a, d1 = (double)b, d2 = 1.5, d3 = 2.5, dm = 1.0000001, da = 0.5;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (OP == 0) {        // v_mad_u64_u32, 4 independent accumulators
+                asm volatile("v_mad_u64_u32 %0, s[6:7], %4, %5, %0\n\t"
+                             "v_mad_u64_u32 %1, s[6:7], %4, %5, %1\n\t"
+                             "v_mad_u64_u32 %2, s[6:7], %4, %5, %2\n\t"
+                             "v_mad_u64_u32 %3, s[6:7], %4, %5, %3"
+                             : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3) : "v"(a), "v"(b) : "s6", "s7");
+            } else if (OP == 1) { // v_mul_lo_u32
+                asm volatile("v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\t"
+                             "v_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+            } else if (OP == 2) { // v_mul_hi_u32
+                asm volatile("v_mul_hi_u32 %0, %0, %4\n\tv_mul_hi_u32 %1, %1, %4\n\t"
+                             "v_mul_hi_u32 %2, %2, %4\n\tv_mul_hi_u32 %3, %3, %4"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+            } else if (OP == 3) { // plain v_add_u32 (full-rate reference)
+                asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\t"
+                             "v_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+            } else if (OP == 4) { // v_fma_f64
+                asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\t"
+                             "v_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dm), "v"(da));
+            } else if (OP == 5) { // v_mad_u32_u24
+                asm volatile("v_mad_u32_u24 %0, %0, %4, %5\n\tv_mad_u32_u24 %1, %1, %4, %5\n\t"
+                             "v_mad_u32_u24 %2, %2, %4, %5\n\tv_mad_u32_u24 %3, %3, %4, %5"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a), "v"(b));
+            } else if (OP == 6) { // carry chain: add_co + addc with the 2 wait states gfx950 needs
+                asm volatile("v_add_co_u32 %0, vcc, %0, %4\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\t"
+                             "s_nop 1\n\tv_addc_co_u32 %2, vcc, %2, %4, vcc\n\ts_nop 1\n\tv_addc_co_u32 %3, vcc, %3, %4, vcc"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a) : "vcc");
+            } else if (OP == 7) { // v_lshl_add_u64 (64-bit add, no carry out)
+                asm volatile("v_lshl_add_u64 %0, %0, 0, %4\n\tv_lshl_add_u64 %1, %1, 0, %4\n\t"
+                             "v_lshl_add_u64 %2, %2, 0, %4\n\tv_lshl_add_u64 %3, %3, 0, %4"
+                             : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3) : "v"(acc0));
+            } else if (OP == 8) { // v_mul_hi_u32_u24
+                asm volatile("v_mul_hi_u32_u24 %0, %0, %4\n\tv_mul_hi_u32_u24 %1, %1, %4\n\t"
+                             "v_mul_hi_u32_u24 %2, %2, %4\n\tv_mul_hi_u32_u24 %3, %3, %4"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a));
+            } else if (OP == 9) { // mad + dependent addc with vcc, spaced by 2 independent mads (pipelined carries)
+                asm volatile("v_mad_u64_u32 %0, s[6:7], %4, %5, %0\n\t"
+                             "v_mad_u64_u32 %1, s[8:9], %4, %5, %1\n\t"
+                             "v_mad_u64_u32 %2, s[10:11], %4, %5, %2\n\t"
+                             "v_addc_co_u32 %3, s[12:13], 0, %3, s[6:7]\n\t"
+                             "v_addc_co_u32 %3, s[12:13], 0, %3, s[8:9]\n\t"
+                             "v_addc_co_u32 %3, s[12:13], 0, %3, s[10:11]\n\t"
+                             "v_mad_u64_u32 %0, s[6:7], %4, %5, %0"
+                             : "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(x3) : "v"(a), "v"(b)
+                             : "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13");
+            }
+        }
+    }
+    u32 r = (u32)acc0 ^ (u32)acc1 ^ (u32)acc2 ^ (u32)acc3 ^ (u32)(acc0 >> 32) ^ x0 ^ x1 ^ x2 ^ x3 ^
+            (u32)d0 ^ (u32)d1 ^ (u32)d2 ^ (u32)d3;
+    if (r == 0x12345678u) out[t] = r;   // keep everything live
+}
+
+template <int OP>
+static double run_rate(const char *name, int per_iter, u32 *dout)
+{
+    const int blocks = 256 * 8, threads = 256, iters = 2000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, dout, 10, 1u);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, dout, iters, 2u);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double n = (double)blocks * threads * iters * 16.0 * per_iter;
+    double gops = n / (ms * 1e-3) / 1e9;
+    // cycles per wave-instruction per SIMD at 2.4 GHz nominal: 256 CU * 4 SIMD
+    double wave_instr_per_s = gops * 1e9 / 64.0;
+    double cyc = 2.4e9 * 256 * 4 / wave_instr_per_s;
+    printf("{\"bench\":\"rate\",\"op\":\"%s\",\"Gops_per_s\":%.1f,\"cycles_per_wave_instr_per_simd_at_2.4GHz\":%.2f,\"ms\":%.3f}\n",
+           name, gops, cyc, ms);
+    return gops;
+}
+
+// ---------------------------------------------------------------- random reads (GUPS)
+__device__ __forceinline__ u64 splitmix(u64 &s)
+{
+    s += 0x9E3779B97F4A7C15ULL;
+    u64 z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// each lane reads GRAN bytes (16*NV) at a random GRAN-aligned offset, UNROLL independent loads in flight
+template <int NV, int UNROLL>
+__global__ void __launch_bounds__(256) gups_kernel(const u32x4 *__restrict__ buf, u64 n_gran, int iters, u32 *out, u64 seed)
+{
+    u64 s = seed + (u64)(threadIdx.x + blockIdx.x * blockDim.x) * 0x632BE59BD9B4E019ULL;
+    u32 acc = 0;
+    for (int i = 0; i < iters; i++) {
+        u32x4 v[UNROLL][NV];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            u64 g = splitmix(s) % n_gran;     // n_gran is a power of two in practice
+            const u32x4 *p = buf + g * NV;
+#pragma unroll
+            for (int k = 0; k < NV; k++) v[u][k] = p[k];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+            for (int k = 0; k < NV; k++) acc ^= v[u][k].x ^ v[u][k].y ^ v[u][k].z ^ v[u][k].w;
+    }
+    if (acc == 0x9abcdef1u) out[0] = acc;
+}
+
+// cooperative: a group of (GRAN/16) lanes reads one granule, each lane 16 B (coalesced inside the granule)
+template <int LANES_PER, int UNROLL>
+__global__ void __launch_bounds__(256) gups_coop_kernel(const u32x4 *__restrict__ buf, u64 n_gran, int iters, u32 *out, u64 seed)
+{
+    u32 tid = threadIdx.x + blockIdx.x * blockDim.x;
+    u64 s = seed + (u64)(tid / LANES_PER) * 0x632BE59BD9B4E019ULL;
+    u32 sub = tid % LANES_PER;
+    u32 acc = 0;
+    for (int i = 0; i < iters; i++) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            u64 g = splitmix(s) % n_gran;
+            v[u] = buf[g * LANES_PER + sub];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x9abcdef1u) out[0] = acc;
+}
+
+template <int NV, int UNROLL>
+static void run_gups(const u32x4 *buf, size_t bytes, u32 *dout, int waves_per_simd)
+{
+    const int threads = 256, blocks = 256 * waves_per_simd;   // waves/SIMD = blocks*4/(256*4)
+    const int iters = 256;
+    u64 n_gran = bytes / (16 * NV);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((gups_kernel<NV, UNROLL>), dim3(blocks), dim3(threads), 0, 0, buf, n_gran, 4, dout, 1ULL);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((gups_kernel<NV, UNROLL>), dim3(blocks), dim3(threads), 0, 0, buf, n_gran, iters, dout, 99ULL);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double reads = (double)blocks * threads * iters * UNROLL;
+    printf("{\"bench\":\"gups\",\"mode\":\"lane\",\"footprint_MiB\":%zu,\"granule_B\":%d,\"in_flight_per_lane\":%d,\"waves_per_simd\":%d,"
+           "\"Greads_per_s\":%.2f,\"GBps\":%.1f,\"ms\":%.3f}\n",
+           bytes >> 20, 16 * NV, UNROLL, waves_per_simd, reads / (ms * 1e-3) / 1e9, reads * 16 * NV / (ms * 1e-3) / 1e9, ms);
+}
+
+template <int LANES_PER, int UNROLL>
+static void run_gups_coop(const u32x4 *buf, size_t bytes, u32 *dout, int waves_per_simd)
+{
+    const int threads = 256, blocks = 256 * waves_per_simd;
+    const int iters = 256;
+    u64 n_gran = bytes / (16 * LANES_PER);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((gups_coop_kernel<LANES_PER, UNROLL>), dim3(blocks), dim3(threads), 0, 0, buf, n_gran, 4, dout, 1ULL);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((gups_coop_kernel<LANES_PER, UNROLL>), dim3(blocks), dim3(threads), 0, 0, buf, n_gran, iters, dout, 99ULL);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double reads = (double)blocks * threads * iters * UNROLL / LANES_PER;
+    printf("{\"bench\":\"gups\",\"mode\":\"coop\",\"footprint_MiB\":%zu,\"granule_B\":%d,\"in_flight_per_lane\":%d,\"waves_per_simd\":%d,"
+           "\"Greads_per_s\":%.2f,\"GBps\":%.1f,\"ms\":%.3f}\n",
+           bytes >> 20, 16 * LANES_PER, UNROLL, waves_per_simd, reads / (ms * 1e-3) / 1e9,
+           reads * 16 * LANES_PER / (ms * 1e-3) / 1e9, ms);
+}
+
+__global__ void fill_kernel(uint4 *buf, size_t n)
+{
+    size_t i = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) buf[i] = make_uint4((u32)i, (u32)(i >> 32), (u32)i * 2654435761u, 7u);
+}
+
+int main(int argc, char **argv)
+{
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("{\"device\":\"%s\",\"cus\":%d,\"clock_MHz\":%d,\"mem_GiB\":%.1f}\n", prop.name, prop.multiProcessorCount,
+           prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
+    u32 *dout; CK(hipMalloc(&dout, 256 * 8 * 256 * 4));
+    run_rate<3>("v_add_u32", 4, dout);
+    run_rate<0>("v_mad_u64_u32", 4, dout);
+    run_rate<1>("v_mul_lo_u32", 4, dout);
+    run_rate<2>("v_mul_hi_u32", 4, dout);
+    run_rate<4>("v_fma_f64", 4, dout);
+    run_rate<5>("v_mad_u32_u24", 4, dout);
+    run_rate<8>("v_mul_hi_u32_u24", 4, dout);
+    run_rate<6>("carry_chain_add_co+3addc(with s_nop 1)", 4, dout);
+    run_rate<7>("v_lshl_add_u64", 4, dout);
+    run_rate<9>("4mad+3addc_pipelined", 7, dout);
+
+    std::vector<size_t> sizes;
+    for (int i = 1; i < argc; i++) sizes.push_back((size_t)atoll(argv[i]) << 20);
+    if (sizes.empty()) { sizes.push_back((size_t)384 << 20); sizes.push_back((size_t)5120 << 20); sizes.push_back((size_t)16384 << 20); }
+    for (size_t bytes : sizes) {
+        uint4 *buf; CK(hipMalloc(&buf, bytes));
+        hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf, bytes / 16);
+        CK(hipDeviceSynchronize());
+        for (int wps : {4, 8}) {
+            run_gups<1, 8>((const u32x4*)buf, bytes, dout, wps);    // 16 B
+            run_gups<2, 8>((const u32x4*)buf, bytes, dout, wps);    // 32 B
+            run_gups<4, 4>((const u32x4*)buf, bytes, dout, wps);    // 64 B
+            run_gups<4, 8>((const u32x4*)buf, bytes, dout, wps);    // 64 B, deeper
+            run_gups<8, 4>((const u32x4*)buf, bytes, dout, wps);    // 128 B
+            run_gups_coop<4, 8>((const u32x4*)buf, bytes, dout, wps);   // 64 B by 4 lanes
+            run_gups_coop<8, 8>((const u32x4*)buf, bytes, dout, wps);   // 128 B by 8 lanes
+        }
+        CK(hipFree(buf));
+    }
+    return 0;
+}
