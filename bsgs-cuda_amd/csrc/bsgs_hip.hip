@@ -1,0 +1,534 @@
+// bsgs_hip.hip -- C-ABI (include/bsgs_hip.h) of the MI355X giant-step engine: native API.
+// Build: see ../Makefile (hipcc --offload-arch=gfx950 -shared -fPIC).  No CPU fallback exists: every
+// entry point fails with BSGS_ERR_HIP when no gfx950 device / runtime is available.
+#include "giant_kernel.hip.h"
+#include "../../include/bsgs_hip.h"
+#include "host_secp.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                        \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) return fail(BSGS_ERR_HIP, "%s -> %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *bsgs_last_error(void) { return g_err.c_str(); }
+extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
+
+struct bsgs_dev {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop;
+    // geometry
+    uint32_t t = 0, b = 0, p = 0;
+    uint64_t T = 0, maxnonce = 0;
+    // buffers
+    u32x4 *g2 = nullptr;        // [p][4][T]
+    u32x4 *chain = nullptr;     // [p][2][T]
+    u32 *csr = nullptr;         // htGPU image
+    bool csr_owned = true;
+    u32x4 *lines = nullptr;
+    uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
+    uint32_t layout = 0;        // 1 csr, 2 lines64, 3 lines128
+    u32 *hitbuf = nullptr;      // device
+    u32 *hit_host = nullptr;    // pinned mirror
+    uint32_t max_hits = 1u << 16;
+    uint32_t queued = 0;
+    bool timing_open = false;
+};
+
+static size_t hitbuf_bytes(const bsgs_dev *d) { return 64 + (size_t)d->max_hits * 16; }
+
+extern "C" int bsgs_dev_count(int *n)
+{
+    if (!n) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipGetDeviceCount(n));
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
+{
+    if (!out) return fail(BSGS_ERR_ARG, "null");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) return fail(BSGS_ERR_ARG, "device %d of %d", device_id, n);
+    HIPCHK(hipSetDevice(device_id));
+    bsgs_dev *d = new bsgs_dev();
+    d->id = device_id;
+    HIPCHK(hipGetDeviceProperties(&d->prop, device_id));
+    HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&d->ev0));
+    HIPCHK(hipEventCreate(&d->ev1));
+    HIPCHK(hipMalloc(&d->hitbuf, hitbuf_bytes(d)));
+    HIPCHK(hipHostMalloc(&d->hit_host, hitbuf_bytes(d), hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(d->hitbuf, 0, 64, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    *out = d;
+    return BSGS_OK;
+}
+
+static void free_table(bsgs_dev *d)
+{
+    if (d->csr && d->csr_owned) (void)hipFree(d->csr);
+    if (d->lines) (void)hipFree(d->lines);
+    d->csr = nullptr; d->lines = nullptr; d->layout = 0;
+}
+static void free_g2(bsgs_dev *d)
+{
+    if (d->g2) (void)hipFree(d->g2);
+    if (d->chain) (void)hipFree(d->chain);
+    d->g2 = nullptr; d->chain = nullptr;
+}
+
+extern "C" int bsgs_dev_close(bsgs_dev *d)
+{
+    if (!d) return BSGS_OK;
+    (void)hipSetDevice(d->id);
+    (void)hipStreamSynchronize(d->stream);
+    free_table(d); free_g2(d);
+    if (d->hitbuf) (void)hipFree(d->hitbuf);
+    if (d->hit_host) (void)hipHostFree(d->hit_host);
+    (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1);
+    (void)hipStreamDestroy(d->stream);
+    delete d;
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_dev_name(bsgs_dev *d, char *buf, int len)
+{
+    if (!d || !buf || len <= 0) return fail(BSGS_ERR_ARG, "bad args");
+    snprintf(buf, (size_t)len, "%s (%s)", d->prop.name, d->prop.gcnArchName);
+    return BSGS_OK;
+}
+extern "C" int bsgs_dev_meminfo(bsgs_dev *d, uint64_t *fr, uint64_t *tot)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (fr) *fr = f;
+    if (tot) *tot = t;
+    return BSGS_OK;
+}
+extern "C" int bsgs_dev_cu_count(bsgs_dev *d, int *cus)
+{
+    if (!d || !cus) return fail(BSGS_ERR_ARG, "null");
+    *cus = d->prop.multiProcessorCount;
+    return BSGS_OK;
+}
+extern "C" int bsgs_dev_stream(bsgs_dev *d, void **s)
+{
+    if (!d || !s) return fail(BSGS_ERR_ARG, "null");
+    *s = (void *)d->stream;
+    return BSGS_OK;
+}
+extern "C" int bsgs_steps_per_tile(bsgs_dev *d, uint64_t *steps)
+{
+    if (!d || !steps) return fail(BSGS_ERR_ARG, "null");
+    *steps = 2 * d->maxnonce;
+    return BSGS_OK;
+}
+
+// ---- giants ------------------------------------------------------------------------------------------
+static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
+{
+    if (!t || !b || !p) return fail(BSGS_ERR_ARG, "t,b,p must be non-zero");
+    const uint64_t T = (uint64_t)t * b, maxnonce = T * p;
+    if (T >= (1ull << 31) || maxnonce >= (1ull << 32)) return fail(BSGS_ERR_ARG, "t*b*p must be < 2^32 (hit index is u32)");
+    HIPCHK(hipSetDevice(d->id));
+    free_g2(d);
+    d->t = t; d->b = b; d->p = p; d->T = T; d->maxnonce = maxnonce;
+    HIPCHK(hipMalloc(&d->g2, maxnonce * 64));
+    HIPCHK(hipMalloc(&d->chain, maxnonce * 32));
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_upload_g2_device(bsgs_dev *d, const void *dimage, uint32_t t, uint32_t b, uint32_t p)
+{
+    if (!d || !dimage) return fail(BSGS_ERR_ARG, "null");
+    int rc = set_geometry(d, t, b, p);
+    if (rc) return rc;
+    const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
+    hipLaunchKernelGGL(g2_relayout_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32 *)dimage, d->g2, (u32)d->T, p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_upload_g2(bsgs_dev *d, const void *image, uint32_t t, uint32_t b, uint32_t p)
+{
+    if (!d || !image) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    const uint64_t bytes = (uint64_t)t * b * p * 64;
+    void *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, bytes));
+    hipError_t e = hipMemcpy(tmp, image, bytes, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? bsgs_upload_g2_device(d, tmp, t, b, p) : fail(BSGS_ERR_HIP, "memcpy: %s", hipGetErrorString(e));
+    (void)hipFree(tmp);
+    return rc;
+}
+
+extern "C" int bsgs_download_g2(bsgs_dev *d, void *image_out, size_t bytes)
+{
+    if (!d || !image_out) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2) return fail(BSGS_ERR_STATE, "no giants on device");
+    if (bytes != d->maxnonce * 64) return fail(BSGS_ERR_ARG, "image must be %llu bytes", (unsigned long long)(d->maxnonce * 64));
+    HIPCHK(hipSetDevice(d->id));
+    void *tmp = nullptr;
+    HIPCHK(hipMalloc(&tmp, bytes));
+    const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
+    hipLaunchKernelGGL(g2_to_image_kernel, dim3(blocks), dim3(256), 0, d->stream, d->g2, (u32 *)tmp, (u32)d->T, d->p);
+    hipError_t e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess) e = hipMemcpy(image_out, tmp, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "download: %s", hipGetErrorString(e));
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_generate_g2(bsgs_dev *d, const uint8_t a_xy_le[64], uint32_t t, uint32_t b, uint32_t p)
+{
+    if (!d || !a_xy_le) return fail(BSGS_ERR_ARG, "null");
+    int rc = set_geometry(d, t, b, p);
+    if (rc) return rc;
+    // host: helper j*A (j = 1..p-1) and bases (tid*p+1)*A, via the host EC library (host_secp.h)
+    hs::Affine A = hs::affine_from_le(a_xy_le, a_xy_le + 32);
+    std::vector<hs::Affine> helper = hs::multiples(A, p > 1 ? p - 1 : 1);             // 1A..(p-1)A
+    std::vector<hs::Affine> bases = hs::strided_multiples(A, 1, p, d->T);              // (1 + tid*p) A
+    std::vector<uint8_t> hbuf((size_t)std::max<uint32_t>(p - 1, 1) * 64), bbuf((size_t)d->T * 64);
+    for (size_t i = 0; i + 1 < p; i++) hs::affine_to_le(helper[i], &hbuf[i * 64], &hbuf[i * 64 + 32]);
+    for (size_t i = 0; i < d->T; i++) hs::affine_to_le(bases[i], &bbuf[i * 64], &bbuf[i * 64 + 32]);
+    void *dh = nullptr, *db = nullptr;
+    HIPCHK(hipMalloc(&dh, hbuf.size()));
+    HIPCHK(hipMalloc(&db, bbuf.size()));
+    HIPCHK(hipMemcpy(dh, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, bbuf.data(), bbuf.size(), hipMemcpyHostToDevice));
+    const int blocks = (int)((d->T + 255) / 256);
+    hipLaunchKernelGGL(g2_generate_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)dh, (const u32x4 *)db,
+                       d->g2, d->chain, (u32)d->T, p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void)hipFree(dh); (void)hipFree(db);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "g2_generate: %s", hipGetErrorString(e));
+    return BSGS_OK;
+}
+
+// ---- baby table -----------------------------------------------------------------------------------------
+static int build_lines(bsgs_dev *d, uint32_t layout)
+{
+    const int lplog = layout == BSGS_TABLE_LINES128 ? 3 : 2;
+    d->lines_bytes = d->ht_items * (64ull << (lplog - 2));
+    HIPCHK(hipMalloc(&d->lines, d->lines_bytes));
+    unsigned long long *ovf = nullptr;
+    HIPCHK(hipMalloc(&ovf, 8));
+    HIPCHK(hipMemsetAsync(ovf, 0, 8, d->stream));
+    const int blocks = (int)std::min<uint64_t>((d->ht_items + 255) / 256, 1u << 20);
+    if (lplog == 2) hipLaunchKernelGGL(lines_build_kernel<2>, dim3(blocks), dim3(256), 0, d->stream, d->csr, (u32 *)d->lines, d->ht_items, ovf);
+    else            hipLaunchKernelGGL(lines_build_kernel<3>, dim3(blocks), dim3(256), 0, d->stream, d->csr, (u32 *)d->lines, d->ht_items, ovf);
+    HIPCHK(hipGetLastError());
+    unsigned long long h = 0;
+    HIPCHK(hipMemcpyAsync(&h, ovf, 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    (void)hipFree(ovf);
+    d->overflow = h;
+    d->layout = layout;
+    return BSGS_OK;
+}
+
+static int finish_table(bsgs_dev *d, uint64_t ht_items, uint64_t w, uint32_t layout)
+{
+    d->ht_items = ht_items; d->w = w;
+    if (layout == BSGS_TABLE_AUTO) {
+        // mean bucket load decides the line size; fall back to CSR when the lines do not fit in free memory
+        const double load = (double)w / (double)ht_items;
+        layout = load <= 5.0 ? BSGS_TABLE_LINES64 : BSGS_TABLE_LINES128;
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        const uint64_t need = ht_items * (layout == BSGS_TABLE_LINES64 ? 64ull : 128ull);
+        if (load > 14.0 || need + (1ull << 30) > fr) layout = BSGS_TABLE_CSR;
+    }
+    if (layout == BSGS_TABLE_CSR) { d->layout = BSGS_TABLE_CSR; d->lines_bytes = 0; d->overflow = 0; return BSGS_OK; }
+    if (layout != BSGS_TABLE_LINES64 && layout != BSGS_TABLE_LINES128) return fail(BSGS_ERR_ARG, "unknown layout %u", layout);
+    return build_lines(d, layout);
+}
+
+static int check_table_args(uint64_t ht_items, uint64_t w)
+{
+    if (!ht_items || (ht_items & (ht_items - 1))) return fail(BSGS_ERR_ARG, "ht_items must be a power of two");
+    if (ht_items > (1ull << 32) || w >= (1ull << 32)) return fail(BSGS_ERR_ARG, "reference format limits: ht_items <= 2^32, w < 2^32");
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_upload_htgpu(bsgs_dev *d, const void *image, uint64_t ht_items, uint64_t w, uint32_t layout)
+{
+    if (!d || !image) return fail(BSGS_ERR_ARG, "null");
+    int rc = check_table_args(ht_items, w);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->id));
+    free_table(d);
+    const uint64_t bytes = 4 * (ht_items + 1) + 4 * w;
+    HIPCHK(hipMalloc(&d->csr, bytes));
+    d->csr_owned = true;
+    HIPCHK(hipMemcpy(d->csr, image, bytes, hipMemcpyHostToDevice));
+    return finish_table(d, ht_items, w, layout);
+}
+
+extern "C" int bsgs_upload_htgpu_device(bsgs_dev *d, const void *dimage, uint64_t ht_items, uint64_t w, uint32_t layout)
+{
+    if (!d || !dimage) return fail(BSGS_ERR_ARG, "null");
+    int rc = check_table_args(ht_items, w);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->id));
+    free_table(d);
+    d->csr = (u32 *)dimage;          // borrowed: the caller keeps the image alive (it is the overflow fallback)
+    d->csr_owned = false;
+    return finish_table(d, ht_items, w, layout);
+}
+
+extern "C" int bsgs_table_info(bsgs_dev *d, uint32_t *layout, uint64_t *device_bytes, uint64_t *overflow_buckets)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (!d->layout) return fail(BSGS_ERR_STATE, "no table on device");
+    if (layout) *layout = d->layout;
+    if (device_bytes) *device_bytes = 4 * (d->ht_items + 1) + 4 * d->w + d->lines_bytes;
+    if (overflow_buckets) *overflow_buckets = d->overflow;
+    return BSGS_OK;
+}
+
+// ---- tiles ------------------------------------------------------------------------------------------------
+static void le_to_fe(fe &f, const uint8_t *le) { memcpy(f.v, le, 32); }
+
+static int launch_tile(bsgs_dev *d, const uint8_t *px, const uint8_t *py, uint32_t seq)
+{
+    TileArgs A;
+    A.g2 = d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.hitbuf = d->hitbuf;
+    A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->p; A.T = (u32)d->T;
+    A.max_hits = d->max_hits; A.tile_seq = seq; A.pad = 0;
+    le_to_fe(A.px, px); le_to_fe(A.py, py);
+    const dim3 grid((unsigned)((d->T + 255) / 256)), block(256);
+    switch (d->layout) {
+    case BSGS_TABLE_LINES64:  hipLaunchKernelGGL(giant_tile_kernel<2>, grid, block, 0, d->stream, A); break;
+    case BSGS_TABLE_LINES128: hipLaunchKernelGGL(giant_tile_kernel<3>, grid, block, 0, d->stream, A); break;
+    default:                  hipLaunchKernelGGL(giant_tile_kernel<0>, grid, block, 0, d->stream, A); break;
+    }
+    HIPCHK(hipGetLastError());
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
+{
+    if (!d || !centres) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
+    HIPCHK(hipSetDevice(d->id));
+    if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); d->timing_open = true; }
+    for (uint32_t k = 0; k < ntiles; k++) {
+        int rc = launch_tile(d, centres + (size_t)k * 64, centres + (size_t)k * 64 + 32, d->queued + k);
+        if (rc) return rc;
+    }
+    d->queued += ntiles;
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_collect(bsgs_dev *d, bsgs_hit_ex *hits, uint32_t max_hits, uint32_t *nhits, float *kernel_ms)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    if (d->timing_open) HIPCHK(hipEventRecord(d->ev1, d->stream));
+    HIPCHK(hipMemcpyAsync(d->hit_host, d->hitbuf, 64, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    uint32_t n = d->hit_host[0];
+    if (kernel_ms) {
+        *kernel_ms = 0.f;
+        if (d->timing_open) HIPCHK(hipEventElapsedTime(kernel_ms, d->ev0, d->ev1));
+    }
+    d->timing_open = false;
+    d->queued = 0;
+    const uint32_t stored = std::min(n, d->max_hits);
+    if (stored) {
+        HIPCHK(hipMemcpyAsync(d->hit_host + BSGS_HIT_HEADER_WORDS, d->hitbuf + BSGS_HIT_HEADER_WORDS, (size_t)stored * 16,
+                              hipMemcpyDeviceToHost, d->stream));
+    }
+    if (n) HIPCHK(hipMemsetAsync(d->hitbuf, 0, 64, d->stream));       // the host zeroes the counter after draining (1_9_7File.pb:2502-2503)
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (nhits) *nhits = n;
+    const bsgs_hit_ex *rec = (const bsgs_hit_ex *)(d->hit_host + BSGS_HIT_HEADER_WORDS);
+    std::vector<bsgs_hit_ex> v(rec, rec + stored);
+    std::sort(v.begin(), v.end(), [](const bsgs_hit_ex &x, const bsgs_hit_ex &y) {
+        if (x.tile != y.tile) return x.tile < y.tile;
+        if (x.idx != y.idx) return x.idx < y.idx;
+        return x.code < y.code;
+    });
+    const uint32_t ncopy = std::min<uint32_t>(stored, max_hits);
+    if (hits && ncopy) memcpy(hits, v.data(), (size_t)ncopy * sizeof(bsgs_hit_ex));
+    if (n > max_hits || n > d->max_hits) return fail(BSGS_ERR_OVERFLOW, "%u hits, room for %u", n, std::min(max_hits, d->max_hits));
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_run(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, bsgs_hit_ex *hits, uint32_t max_hits,
+                        uint32_t *nhits, float *kernel_ms)
+{
+    int rc = bsgs_enqueue(d, centres, ntiles);
+    if (rc) return rc;
+    return bsgs_collect(d, hits, max_hits, nhits, kernel_ms);
+}
+
+extern "C" int bsgs_step(bsgs_dev *d, const uint8_t px_le[32], const uint8_t py_le[32], bsgs_hit *hits, uint32_t max_hits,
+                         uint32_t *nhits)
+{
+    if (!d || !px_le || !py_le) return fail(BSGS_ERR_ARG, "null");
+    uint8_t c[64];
+    memcpy(c, px_le, 32); memcpy(c + 32, py_le, 32);
+    std::vector<bsgs_hit_ex> ex(max_hits ? max_hits : 1);
+    uint32_t n = 0;
+    int rc = bsgs_run(d, c, 1, ex.data(), max_hits, &n, nullptr);
+    if (nhits) *nhits = n;
+    if (rc && rc != BSGS_ERR_OVERFLOW) return rc;
+    const uint32_t m = std::min(n, max_hits);
+    for (uint32_t i = 0; i < m && hits; i++) { hits[i].code = ex[i].code; hits[i].idx = ex[i].idx; }
+    return rc;
+}
+
+// ---- selftests ----------------------------------------------------------------------------------------------
+extern "C" int bsgs_selftest_fe(bsgs_dev *d, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, uint32_t n)
+{
+    if (!d || !a || !b || !out) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    fe *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(&da, (size_t)n * 32)); HIPCHK(hipMalloc(&db, (size_t)n * 32)); HIPCHK(hipMalloc(&dout, (size_t)n * 32));
+    HIPCHK(hipMemcpy(da, a, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, (size_t)n * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fe_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, d->stream, op, da, db, dout, n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "selftest_fe: %s", hipGetErrorString(e));
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_selftest_xs(bsgs_dev *d, const uint8_t px_le[32], const uint8_t py_le[32], uint64_t first, uint32_t count, uint8_t *out)
+{
+    if (!d || !px_le || !py_le || !out) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2) return fail(BSGS_ERR_STATE, "no giants");
+    if (first + count > d->maxnonce) return fail(BSGS_ERR_ARG, "range beyond maxnonce");
+    HIPCHK(hipSetDevice(d->id));
+    fe *dout = nullptr;
+    HIPCHK(hipMalloc(&dout, (size_t)count * 96));
+    fe Px, Py;
+    le_to_fe(Px, px_le); le_to_fe(Py, py_le);
+    hipLaunchKernelGGL(xs_selftest_kernel, dim3((count + 63) / 64), dim3(64), 0, d->stream, d->g2, (u32)d->T, d->p, Px, Py, first, count, dout);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)count * 96, hipMemcpyDeviceToHost);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "selftest_xs: %s", hipGetErrorString(e));
+    return BSGS_OK;
+}
+
+// ---- roofline denominators ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 mb_splitmix(u64 &s)
+{
+    s += 0x9E3779B97F4A7C15ULL;
+    u64 z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+template <int LP>
+__global__ void __launch_bounds__(256) mb_gups_kernel(const u32x4 *__restrict__ buf, u64 n_gran_mask, int iters, u32 *out, u64 seed)
+{
+    const u32 tid = threadIdx.x + blockIdx.x * blockDim.x;
+    u64 s = seed + (u64)(tid / LP) * 0x632BE59BD9B4E019ULL;
+    const u32 sub = tid % LP;
+    u32 acc = 0;
+    for (int i = 0; i < iters; i++) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = buf[(mb_splitmix(s) & n_gran_mask) * LP + sub];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x9abcdef1u) out[0] = acc;
+}
+
+extern "C" int bsgs_bench_random_read(bsgs_dev *d, uint64_t footprint_bytes, uint32_t granule, double *gbps, double *greads)
+{
+    if (!d || (granule != 64 && granule != 128)) return fail(BSGS_ERR_ARG, "granule must be 64 or 128");
+    HIPCHK(hipSetDevice(d->id));
+    uint64_t n = 1;
+    while (n * 2 * granule <= footprint_bytes) n *= 2;         // power-of-two granule count
+    void *buf = nullptr; u32 *out = nullptr;
+    HIPCHK(hipMalloc(&buf, n * granule));
+    HIPCHK(hipMalloc(&out, 64));
+    HIPCHK(hipMemsetAsync(buf, 0x5a, n * granule, d->stream));
+    const int blocks = 256 * 8, iters = 256;
+    const int LP = (int)granule / 16;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; rep++) {
+        HIPCHK(hipEventRecord(e0, d->stream));
+        if (LP == 4) hipLaunchKernelGGL(mb_gups_kernel<4>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)buf, n - 1, iters, out, 17ull + rep);
+        else         hipLaunchKernelGGL(mb_gups_kernel<8>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)buf, n - 1, iters, out, 17ull + rep);
+        HIPCHK(hipEventRecord(e1, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+    }
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    const double reads = (double)blocks * 256 * iters * 8 / LP;
+    if (greads) *greads = reads / (ms * 1e-3) / 1e9;
+    if (gbps) *gbps = reads * granule / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(buf); (void)hipFree(out);
+    return BSGS_OK;
+}
+
+__global__ void __launch_bounds__(256) mb_modmul_kernel(fe *out, int iters, u32 seed)
+{
+    const u32 t = threadIdx.x + blockIdx.x * blockDim.x;
+    fe a, b;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a.v[i] = seed * 2654435761u + t * 40503u + i; b.v[i] = a.v[i] ^ 0x9E3779B9u; }
+    for (int i = 0; i < iters; i++) { fe_mul(a, a, b); fe_mul(b, b, a); }
+    if (a.v[0] == 0x12345678u && b.v[3] == 7u) out[t] = a;
+}
+
+extern "C" int bsgs_bench_modmul(bsgs_dev *d, double *gmul)
+{
+    if (!d || !gmul) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    const int blocks = 256 * 8, iters = 2000;
+    fe *out = nullptr;
+    HIPCHK(hipMalloc(&out, (size_t)blocks * 256 * 32));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mb_modmul_kernel, dim3(blocks), dim3(256), 0, d->stream, out, 10, 1u);
+    HIPCHK(hipEventRecord(e0, d->stream));
+    hipLaunchKernelGGL(mb_modmul_kernel, dim3(blocks), dim3(256), 0, d->stream, out, iters, 2u);
+    HIPCHK(hipEventRecord(e1, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *gmul = (double)blocks * 256 * iters * 2 / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return BSGS_OK;
+}

@@ -1,0 +1,224 @@
+"""pybsgs -- thin ctypes binding of libbsgs_hip.so (include/bsgs_hip.h).
+
+Plumbing only: every call goes straight to the C-ABI; there is NO CPU fallback.  Importing works
+without a GPU (so CPU-only checks can verify the exported symbols); opening a device without an
+MI355X raises BsgsError.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(PKG_ROOT, "build", "libbsgs_hip.so")
+
+TABLE_AUTO, TABLE_CSR, TABLE_LINES64, TABLE_LINES128 = 0, 1, 2, 3
+ERR_OVERFLOW = -5
+
+# every symbol include/bsgs_hip.h declares (checked by tests/test_abi.py)
+NATIVE_SYMBOLS = [
+    "bsgs_last_error", "bsgs_version", "bsgs_dev_count", "bsgs_dev_open", "bsgs_dev_close", "bsgs_dev_name",
+    "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
+    "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
+    "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
+    "bsgs_bench_random_read", "bsgs_bench_modmul",
+]
+COMPAT_SYMBOLS = [
+    "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
+    "cuDeviceGetAttribute", "cuCtxCreate_v2", "cuCtxDestroy_v2", "cuCtxSynchronize", "cuMemGetInfo_v2", "cuModuleLoadData",
+    "cuModuleGetFunction", "cuModuleGetGlobal_v2", "cuFuncSetCacheConfig", "cuFuncSetBlockShape", "cuParamSetSize",
+    "cuParamSeti", "cuMemAlloc_v2", "cuMemFree_v2", "cuMemcpyHtoD_v2", "cuMemcpyDtoH_v2", "cuLaunchGrid",
+]
+
+
+class BsgsError(RuntimeError):
+    pass
+
+
+class Hit(C.Structure):
+    _fields_ = [("code", C.c_uint32), ("idx", C.c_uint32)]
+
+
+class HitEx(C.Structure):
+    _fields_ = [("code", C.c_uint32), ("idx", C.c_uint32), ("tile", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BsgsError("HIP extension missing: %s (run `make -C bsgs-cuda_amd` or __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u8p = C.c_void_p, C.c_char_p
+        L.bsgs_last_error.restype = C.c_char_p
+        L.bsgs_version.restype = C.c_char_p
+        sig = {
+            "bsgs_dev_count": [C.POINTER(C.c_int)],
+            "bsgs_dev_open": [C.c_int, C.POINTER(vp)],
+            "bsgs_dev_close": [vp],
+            "bsgs_dev_name": [vp, C.c_char_p, C.c_int],
+            "bsgs_dev_meminfo": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+            "bsgs_dev_cu_count": [vp, C.POINTER(C.c_int)],
+            "bsgs_upload_g2": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32],
+            "bsgs_upload_g2_device": [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32],
+            "bsgs_generate_g2": [vp, u8p, C.c_uint32, C.c_uint32, C.c_uint32],
+            "bsgs_download_g2": [vp, vp, C.c_size_t],
+            "bsgs_upload_htgpu": [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32],
+            "bsgs_upload_htgpu_device": [vp, vp, C.c_uint64, C.c_uint64, C.c_uint32],
+            "bsgs_table_info": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+            "bsgs_step": [vp, u8p, u8p, C.POINTER(Hit), C.c_uint32, C.POINTER(C.c_uint32)],
+            "bsgs_run": [vp, u8p, C.c_uint32, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)],
+            "bsgs_enqueue": [vp, u8p, C.c_uint32],
+            "bsgs_collect": [vp, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)],
+            "bsgs_dev_stream": [vp, C.POINTER(vp)],
+            "bsgs_steps_per_tile": [vp, C.POINTER(C.c_uint64)],
+            "bsgs_selftest_fe": [vp, C.c_int, u8p, u8p, vp, C.c_uint32],
+            "bsgs_selftest_xs": [vp, u8p, u8p, C.c_uint64, C.c_uint32, vp],
+            "bsgs_bench_random_read": [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+            "bsgs_bench_modmul": [vp, C.POINTER(C.c_double)],
+        }
+        for name, args in sig.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _chk(rc, allow_overflow=False):
+    if rc == 0 or (allow_overflow and rc == ERR_OVERFLOW):
+        return rc
+    raise BsgsError("bsgs error %d: %s" % (rc, lib().bsgs_last_error().decode()))
+
+
+def le32(v):
+    return int(v).to_bytes(32, "little")
+
+
+def device_count():
+    n = C.c_int(0)
+    _chk(lib().bsgs_dev_count(C.byref(n)))
+    return n.value
+
+
+class Device:
+    """One GPU, mirroring the reference's per-GPU driver thread `cuda()` (1_9_7File.pb:2095-2553)."""
+
+    def __init__(self, device_id=0):
+        self.h = C.c_void_p()
+        _chk(lib().bsgs_dev_open(device_id, C.byref(self.h)))
+        self.L = lib()
+
+    def close(self):
+        if self.h:
+            self.L.bsgs_dev_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def name(self):
+        buf = C.create_string_buffer(256)
+        _chk(self.L.bsgs_dev_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def meminfo(self):
+        f, t = C.c_uint64(), C.c_uint64()
+        _chk(self.L.bsgs_dev_meminfo(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def upload_g2(self, image, t, b, p):
+        buf = C.create_string_buffer(image, len(image)) if isinstance(image, (bytes, bytearray)) else image
+        _chk(self.L.bsgs_upload_g2(self.h, C.cast(buf, C.c_void_p), t, b, p))
+
+    def upload_g2_device(self, dptr, t, b, p):
+        _chk(self.L.bsgs_upload_g2_device(self.h, C.c_void_p(dptr), t, b, p))
+
+    def generate_g2(self, ax, ay, t, b, p):
+        _chk(self.L.bsgs_generate_g2(self.h, le32(ax) + le32(ay), t, b, p))
+
+    def download_g2(self, nbytes):
+        buf = C.create_string_buffer(nbytes)
+        _chk(self.L.bsgs_download_g2(self.h, C.cast(buf, C.c_void_p), nbytes))
+        return buf.raw
+
+    def upload_htgpu(self, image, ht_items, w, layout=TABLE_AUTO):
+        buf = C.create_string_buffer(image, len(image)) if isinstance(image, (bytes, bytearray)) else image
+        _chk(self.L.bsgs_upload_htgpu(self.h, C.cast(buf, C.c_void_p), ht_items, w, layout))
+
+    def upload_htgpu_device(self, dptr, ht_items, w, layout=TABLE_AUTO):
+        _chk(self.L.bsgs_upload_htgpu_device(self.h, C.c_void_p(dptr), ht_items, w, layout))
+
+    def table_info(self):
+        lay, nb, ov = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _chk(self.L.bsgs_table_info(self.h, C.byref(lay), C.byref(nb), C.byref(ov)))
+        return lay.value, nb.value, ov.value
+
+    def step(self, px, py, max_hits=4096):
+        hits = (Hit * max_hits)()
+        n = C.c_uint32()
+        _chk(self.L.bsgs_step(self.h, le32(px), le32(py), hits, max_hits, C.byref(n)), allow_overflow=True)
+        return [(hits[i].code, hits[i].idx) for i in range(min(n.value, max_hits))], n.value
+
+    def run(self, centres, max_hits=65536):
+        """centres: list of (x, y) ints.  Returns (hits [(tile, code, idx)], total, kernel_ms)."""
+        blob = b"".join(le32(x) + le32(y) for x, y in centres)
+        return self.run_raw(blob, len(centres), max_hits)
+
+    def run_raw(self, blob, ntiles, max_hits=65536):
+        hits = (HitEx * max_hits)()
+        n, ms = C.c_uint32(), C.c_float()
+        _chk(self.L.bsgs_run(self.h, blob, ntiles, hits, max_hits, C.byref(n), C.byref(ms)), allow_overflow=True)
+        return [(hits[i].tile, hits[i].code, hits[i].idx) for i in range(min(n.value, max_hits))], n.value, ms.value
+
+    def enqueue_raw(self, blob, ntiles):
+        _chk(self.L.bsgs_enqueue(self.h, blob, ntiles))
+
+    def collect(self, max_hits=65536):
+        hits = (HitEx * max_hits)()
+        n, ms = C.c_uint32(), C.c_float()
+        _chk(self.L.bsgs_collect(self.h, hits, max_hits, C.byref(n), C.byref(ms)), allow_overflow=True)
+        return [(hits[i].tile, hits[i].code, hits[i].idx) for i in range(min(n.value, max_hits))], n.value, ms.value
+
+    def steps_per_tile(self):
+        s = C.c_uint64()
+        _chk(self.L.bsgs_steps_per_tile(self.h, C.byref(s)))
+        return s.value
+
+    def stream(self):
+        s = C.c_void_p()
+        _chk(self.L.bsgs_dev_stream(self.h, C.byref(s)))
+        return s.value
+
+    def selftest_fe(self, op, a_list, b_list):
+        n = len(a_list)
+        a = b"".join(le32(v) for v in a_list)
+        b = b"".join(le32(v) for v in b_list)
+        out = C.create_string_buffer(32 * n)
+        _chk(self.L.bsgs_selftest_fe(self.h, op, a, b, C.cast(out, C.c_void_p), n))
+        return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+
+    def selftest_xs(self, px, py, first, count):
+        out = C.create_string_buffer(96 * count)
+        _chk(self.L.bsgs_selftest_xs(self.h, le32(px), le32(py), first, count, C.cast(out, C.c_void_p)))
+        r = []
+        for k in range(count):
+            v = [int.from_bytes(out.raw[96 * k + 32 * i:96 * k + 32 * i + 32], "little") for i in range(3)]
+            r.append((v[0], v[1], v[2] & 1))
+        return r
+
+    def bench_random_read(self, footprint_bytes, granule=64):
+        g, r = C.c_double(), C.c_double()
+        _chk(self.L.bsgs_bench_random_read(self.h, footprint_bytes, granule, C.byref(g), C.byref(r)))
+        return g.value, r.value
+
+    def bench_modmul(self):
+        g = C.c_double()
+        _chk(self.L.bsgs_bench_modmul(self.h, C.byref(g)))
+        return g.value
