@@ -135,7 +135,7 @@ def _planted_case(O, seed, t, b, p, w, htsz, nplant, tiles):
 @pytest.mark.parametrize("htsz", [14, 12, 10])          # mean bucket load 4, 16, 64: lines / partial / all-overflow
 def test_planted_tiles_match_oracle(dev, O, layout, htsz):
     t, b, p, w = 64, 5, 12, 1 << 16                      # T = 320 (tail wave: 64 live lanes of the second block)
-    g2, gpu, centres = _planted_case(O, 1000 + htsz, t, b, p, w, 24, 4)
+    g2, gpu, centres = _planted_case(O, 1000 + htsz, t, b, p, w, htsz, 24, 4)
     dev.upload_g2(g2, t, b, p)
     dev.upload_htgpu(gpu, 1 << htsz, w, layout)
     lay, _, ovf = dev.table_info()
