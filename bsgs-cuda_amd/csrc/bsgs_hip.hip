@@ -53,6 +53,8 @@ struct bsgs_dev {
     u32 *hit_host = nullptr;    // pinned mirror
     uint32_t max_hits = 1u << 16;
     uint32_t queued = 0;
+    uint32_t tiles_per_launch = BSGS_TILES_PER_LAUNCH;
+    uint64_t launches = 0;
     bool timing_open = false;
 };
 
@@ -148,6 +150,19 @@ extern "C" int bsgs_steps_per_tile(bsgs_dev *d, uint64_t *steps)
     return BSGS_OK;
 }
 
+extern "C" int bsgs_set_tiles_per_launch(bsgs_dev *d, uint32_t n)
+{
+    if (!d || n < 1 || n > BSGS_TILES_PER_LAUNCH) return fail(BSGS_ERR_ARG, "tiles per launch must be 1..%d", BSGS_TILES_PER_LAUNCH);
+    d->tiles_per_launch = n;
+    return BSGS_OK;
+}
+extern "C" int bsgs_launch_count(bsgs_dev *d, uint64_t *launches)
+{
+    if (!d || !launches) return fail(BSGS_ERR_ARG, "null");
+    *launches = d->launches;
+    return BSGS_OK;
+}
+
 // ---- giants ------------------------------------------------------------------------------------------
 static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
 {
@@ -158,7 +173,7 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     free_g2(d);
     d->t = t; d->b = b; d->p = p; d->T = T; d->maxnonce = maxnonce;
     HIPCHK(hipMalloc(&d->g2, maxnonce * 64));
-    HIPCHK(hipMalloc(&d->chain, maxnonce * 32));
+    HIPCHK(hipMalloc(&d->chain, maxnonce * 32 * BSGS_TILES_PER_LAUNCH));
     return BSGS_OK;
 }
 
@@ -316,14 +331,18 @@ extern "C" int bsgs_table_info(bsgs_dev *d, uint32_t *layout, uint64_t *device_b
 // ---- tiles ------------------------------------------------------------------------------------------------
 static void le_to_fe(fe &f, const uint8_t *le) { memcpy(f.v, le, 32); }
 
-static int launch_tile(bsgs_dev *d, const uint8_t *px, const uint8_t *py, uint32_t seq)
+static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq)
 {
     TileArgs A;
     A.g2 = d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.hitbuf = d->hitbuf;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->p; A.T = (u32)d->T;
-    A.max_hits = d->max_hits; A.tile_seq = seq; A.pad = 0;
-    le_to_fe(A.px, px); le_to_fe(A.py, py);
-    const dim3 grid((unsigned)((d->T + 255) / 256)), block(256);
+    A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
+    memset(A.centre, 0, sizeof A.centre);
+    for (uint32_t k = 0; k < ntiles; k++) {
+        le_to_fe(A.centre[2 * k], centres + (size_t)k * 64);
+        le_to_fe(A.centre[2 * k + 1], centres + (size_t)k * 64 + 32);
+    }
+    const dim3 grid((unsigned)(((d->T + 255) / 256) * ntiles)), block(256);
     switch (d->layout) {
     case BSGS_TABLE_LINES64:  hipLaunchKernelGGL(giant_tile_kernel<2>, grid, block, 0, d->stream, A); break;
     case BSGS_TABLE_LINES128: hipLaunchKernelGGL(giant_tile_kernel<3>, grid, block, 0, d->stream, A); break;
@@ -339,9 +358,11 @@ extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles
     if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
     HIPCHK(hipSetDevice(d->id));
     if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); d->timing_open = true; }
-    for (uint32_t k = 0; k < ntiles; k++) {
-        int rc = launch_tile(d, centres + (size_t)k * 64, centres + (size_t)k * 64 + 32, d->queued + k);
+    for (uint32_t k = 0; k < ntiles; k += d->tiles_per_launch) {
+        const uint32_t n = std::min<uint32_t>(d->tiles_per_launch, ntiles - k);
+        int rc = launch_tiles(d, centres + (size_t)k * 64, n, d->queued + k);
         if (rc) return rc;
+        d->launches++;
     }
     d->queued += ntiles;
     return BSGS_OK;

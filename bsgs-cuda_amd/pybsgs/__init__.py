@@ -20,7 +20,7 @@ NATIVE_SYMBOLS = [
     "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
-    "bsgs_bench_random_read", "bsgs_bench_modmul",
+    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -79,6 +79,8 @@ def lib():
             "bsgs_selftest_xs": [vp, u8p, u8p, C.c_uint64, C.c_uint32, vp],
             "bsgs_bench_random_read": [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
             "bsgs_bench_modmul": [vp, C.POINTER(C.c_double)],
+            "bsgs_set_tiles_per_launch": [vp, C.c_uint32],
+            "bsgs_launch_count": [vp, C.POINTER(C.c_uint64)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -185,6 +187,14 @@ class Device:
         n, ms = C.c_uint32(), C.c_float()
         _chk(self.L.bsgs_collect(self.h, hits, max_hits, C.byref(n), C.byref(ms)), allow_overflow=True)
         return [(hits[i].tile, hits[i].code, hits[i].idx) for i in range(min(n.value, max_hits))], n.value, ms.value
+
+    def set_tiles_per_launch(self, n):
+        _chk(self.L.bsgs_set_tiles_per_launch(self.h, n))
+
+    def launch_count(self):
+        n = C.c_uint64()
+        _chk(self.L.bsgs_launch_count(self.h, C.byref(n)))
+        return n.value
 
     def steps_per_tile(self):
         s = C.c_uint64()
