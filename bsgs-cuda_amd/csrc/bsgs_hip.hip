@@ -55,6 +55,7 @@ struct bsgs_dev {
     uint32_t queued = 0;
     uint32_t tiles_per_launch = BSGS_TILES_PER_LAUNCH;
     uint64_t launches = 0;
+    int variant = 1;            // 0 synchronous probes, 1 pipelined probes, 2 + prefetched giants (BSGS_KERNEL_VARIANT)
     bool timing_open = false;
 };
 
@@ -76,6 +77,7 @@ extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
     HIPCHK(hipSetDevice(device_id));
     bsgs_dev *d = new bsgs_dev();
     d->id = device_id;
+    if (const char *v = getenv("BSGS_KERNEL_VARIANT")) d->variant = atoi(v);      // tuning/A-B only; all variants are bit-identical
     HIPCHK(hipGetDeviceProperties(&d->prop, device_id));
     HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&d->ev0));
@@ -343,11 +345,14 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
         le_to_fe(A.centre[2 * k + 1], centres + (size_t)k * 64 + 32);
     }
     const dim3 grid((unsigned)(((d->T + 255) / 256) * ntiles)), block(256);
+    const int var = d->variant;
+#define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, 0, d->stream, A)
     switch (d->layout) {
-    case BSGS_TABLE_LINES64:  hipLaunchKernelGGL(giant_tile_kernel<2>, grid, block, 0, d->stream, A); break;
-    case BSGS_TABLE_LINES128: hipLaunchKernelGGL(giant_tile_kernel<3>, grid, block, 0, d->stream, A); break;
-    default:                  hipLaunchKernelGGL(giant_tile_kernel<0>, grid, block, 0, d->stream, A); break;
+    case BSGS_TABLE_LINES64:  if (var == 0) LAUNCH(2, 0); else if (var == 1) LAUNCH(2, 1); else LAUNCH(2, 2); break;
+    case BSGS_TABLE_LINES128: if (var == 0) LAUNCH(3, 0); else if (var == 1) LAUNCH(3, 1); else LAUNCH(3, 2); break;
+    default:                  LAUNCH(0, 0); break;
     }
+#undef LAUNCH
     HIPCHK(hipGetLastError());
     return BSGS_OK;
 }
