@@ -35,15 +35,19 @@ extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
 
 struct bsgs_dev {
     int id = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;          // main stream: uploads, relayouts, even launches
+    hipStream_t stream2 = nullptr;         // odd launches: the next launch's blocks fill the tail of the previous one
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, evj = nullptr;
+    int nstreams = 1;                      // 2 = alternate launches over two streams (BSGS_STREAMS=2; faster on average, noisier)
     hipDeviceProp_t prop;
     // geometry
-    uint32_t t = 0, b = 0, p = 0;
+    uint32_t t = 0, b = 0, p = 0;          // the caller's geometry (file layout, hit index i = tid*p + j)
     uint64_t T = 0, maxnonce = 0;
+    uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
+    uint64_t chain_tiles = 0;              // tiles the chain scratch is currently sized for
     // buffers
     u32x4 *g2 = nullptr;        // [p][4][T]
-    u32x4 *chain = nullptr;     // [p][2][T]
+    u32x4 *chain = nullptr;     // [stream][tile][p][2][T]
     u32 *csr = nullptr;         // htGPU image
     bool csr_owned = true;
     u32x4 *lines = nullptr;
@@ -53,7 +57,7 @@ struct bsgs_dev {
     u32 *hit_host = nullptr;    // pinned mirror
     uint32_t max_hits = 1u << 16;
     uint32_t queued = 0;
-    uint32_t tiles_per_launch = BSGS_TILES_PER_LAUNCH;
+    uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
     uint64_t launches = 0;
     int variant = 1;            // 0 synchronous probes, 1 pipelined probes, 2 + prefetched giants (BSGS_KERNEL_VARIANT)
     bool timing_open = false;
@@ -80,8 +84,12 @@ extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
     if (const char *v = getenv("BSGS_KERNEL_VARIANT")) d->variant = atoi(v);      // tuning/A-B only; all variants are bit-identical
     HIPCHK(hipGetDeviceProperties(&d->prop, device_id));
     HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&d->ev0));
     HIPCHK(hipEventCreate(&d->ev1));
+    HIPCHK(hipEventCreate(&d->ev2));
+    HIPCHK(hipEventCreateWithFlags(&d->evj, hipEventDisableTiming));
+    if (const char *v = getenv("BSGS_STREAMS")) d->nstreams = atoi(v) == 2 ? 2 : 1;     // tuning / A-B only
     HIPCHK(hipMalloc(&d->hitbuf, hitbuf_bytes(d)));
     HIPCHK(hipHostMalloc(&d->hit_host, hitbuf_bytes(d), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(d->hitbuf, 0, 64, d->stream));
@@ -111,8 +119,9 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     free_table(d); free_g2(d);
     if (d->hitbuf) (void)hipFree(d->hitbuf);
     if (d->hit_host) (void)hipHostFree(d->hit_host);
-    (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1);
-    (void)hipStreamDestroy(d->stream);
+    (void)hipStreamSynchronize(d->stream2);
+    (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->evj);
+    (void)hipStreamDestroy(d->stream); (void)hipStreamDestroy(d->stream2);
     delete d;
     return BSGS_OK;
 }
@@ -154,7 +163,7 @@ extern "C" int bsgs_steps_per_tile(bsgs_dev *d, uint64_t *steps)
 
 extern "C" int bsgs_set_tiles_per_launch(bsgs_dev *d, uint32_t n)
 {
-    if (!d || n < 1 || n > BSGS_TILES_PER_LAUNCH) return fail(BSGS_ERR_ARG, "tiles per launch must be 1..%d", BSGS_TILES_PER_LAUNCH);
+    if (!d || n > BSGS_TILES_PER_LAUNCH) return fail(BSGS_ERR_ARG, "tiles per launch must be 0 (auto) or 1..%d", BSGS_TILES_PER_LAUNCH);
     d->tiles_per_launch = n;
     return BSGS_OK;
 }
@@ -174,9 +183,36 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     HIPCHK(hipSetDevice(d->id));
     free_g2(d);
     d->t = t; d->b = b; d->p = p; d->T = T; d->maxnonce = maxnonce;
+    // Internal batching: one Fermat inversion (270 multiplications) is shared by pi giants of a thread, so a
+    // longer batch is cheaper per giant step; the thread count lost that way is won back by putting more tiles
+    // in one launch.  Grow pi up to ~2048 while Ti stays a multiple of 256 threads and >= 2048.
+    uint32_t m = 1;
+    if (const char *e = getenv("BSGS_BATCH_MULT")) m = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 1;     // tuning / A-B only
+    else while ((uint64_t)p * m * 2 <= 1024 && T % (2ull * m) == 0 && T / (2ull * m) >= 2048 && (T / (2ull * m)) % 256 == 0) m *= 2;
+    if (T % m) m = 1;
+    d->Ti = (uint32_t)(T / m); d->pi = p * m;
+    d->chain_tiles = 0;
     HIPCHK(hipMalloc(&d->g2, maxnonce * 64));
-    HIPCHK(hipMalloc(&d->chain, maxnonce * 32 * BSGS_TILES_PER_LAUNCH));
     return BSGS_OK;
+}
+
+// the prefix-product scratch: 32 bytes per giant per tile in flight
+static int ensure_chain(bsgs_dev *d, uint64_t tiles)
+{
+    if (d->chain && d->chain_tiles >= tiles) return BSGS_OK;
+    if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; }
+    HIPCHK(hipMalloc(&d->chain, d->maxnonce * 32 * tiles * 2));          // one scratch per stream
+    d->chain_tiles = tiles;
+    return BSGS_OK;
+}
+static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
+{
+    if (d->tiles_per_launch) return d->tiles_per_launch;
+    // 4 waves per SIMD fill the chip; with two alternating streams each launch carries half of that, so the
+    // next launch's blocks start as the previous one's drain (no tail between launches)
+    const uint64_t want = (uint64_t)d->prop.multiProcessorCount * (d->nstreams == 2 ? 512 : 2048);   // single stream: two rounds of blocks per launch
+    uint64_t n = (want + d->Ti - 1) / d->Ti;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n, 1), BSGS_TILES_PER_LAUNCH);
 }
 
 extern "C" int bsgs_upload_g2_device(bsgs_dev *d, const void *dimage, uint32_t t, uint32_t b, uint32_t p)
@@ -185,7 +221,7 @@ extern "C" int bsgs_upload_g2_device(bsgs_dev *d, const void *dimage, uint32_t t
     int rc = set_geometry(d, t, b, p);
     if (rc) return rc;
     const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
-    hipLaunchKernelGGL(g2_relayout_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32 *)dimage, d->g2, (u32)d->T, p);
+    hipLaunchKernelGGL(g2_relayout_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32 *)dimage, d->g2, (u32)d->T, p, d->Ti, d->pi);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(d->stream));
     return BSGS_OK;
@@ -213,7 +249,7 @@ extern "C" int bsgs_download_g2(bsgs_dev *d, void *image_out, size_t bytes)
     void *tmp = nullptr;
     HIPCHK(hipMalloc(&tmp, bytes));
     const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
-    hipLaunchKernelGGL(g2_to_image_kernel, dim3(blocks), dim3(256), 0, d->stream, d->g2, (u32 *)tmp, (u32)d->T, d->p);
+    hipLaunchKernelGGL(g2_to_image_kernel, dim3(blocks), dim3(256), 0, d->stream, d->g2, (u32 *)tmp, (u32)d->T, d->p, d->Ti, d->pi);
     hipError_t e = hipStreamSynchronize(d->stream);
     if (e == hipSuccess) e = hipMemcpy(image_out, tmp, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(tmp);
@@ -228,19 +264,22 @@ extern "C" int bsgs_generate_g2(bsgs_dev *d, const uint8_t a_xy_le[64], uint32_t
     if (rc) return rc;
     // host: helper j*A (j = 1..p-1) and bases (tid*p+1)*A, via the host EC library (host_secp.h)
     hs::Affine A = hs::affine_from_le(a_xy_le, a_xy_le + 32);
-    std::vector<hs::Affine> helper = hs::multiples(A, p > 1 ? p - 1 : 1);             // 1A..(p-1)A
-    std::vector<hs::Affine> bases = hs::strided_multiples(A, 1, p, d->T);              // (1 + tid*p) A
-    std::vector<uint8_t> hbuf((size_t)std::max<uint32_t>(p - 1, 1) * 64), bbuf((size_t)d->T * 64);
-    for (size_t i = 0; i + 1 < p; i++) hs::affine_to_le(helper[i], &hbuf[i * 64], &hbuf[i * 64 + 32]);
-    for (size_t i = 0; i < d->T; i++) hs::affine_to_le(bases[i], &bbuf[i * 64], &bbuf[i * 64 + 32]);
+    const uint32_t pi = d->pi, Ti = d->Ti;
+    std::vector<hs::Affine> helper = hs::multiples(A, pi > 1 ? pi - 1 : 1);            // 1A..(pi-1)A
+    std::vector<hs::Affine> bases = hs::strided_multiples(A, 1, pi, Ti);                // (1 + tid*pi) A
+    std::vector<uint8_t> hbuf((size_t)std::max<uint32_t>(pi - 1, 1) * 64), bbuf((size_t)Ti * 64);
+    for (size_t i = 0; i + 1 < pi; i++) hs::affine_to_le(helper[i], &hbuf[i * 64], &hbuf[i * 64 + 32]);
+    for (size_t i = 0; i < Ti; i++) hs::affine_to_le(bases[i], &bbuf[i * 64], &bbuf[i * 64 + 32]);
     void *dh = nullptr, *db = nullptr;
     HIPCHK(hipMalloc(&dh, hbuf.size()));
     HIPCHK(hipMalloc(&db, bbuf.size()));
     HIPCHK(hipMemcpy(dh, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(db, bbuf.data(), bbuf.size(), hipMemcpyHostToDevice));
-    const int blocks = (int)((d->T + 255) / 256);
+    const int blocks = (int)((Ti + 255) / 256);
+    int rcc = ensure_chain(d, 1);
+    if (rcc) { (void)hipFree(dh); (void)hipFree(db); return rcc; }
     hipLaunchKernelGGL(g2_generate_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)dh, (const u32x4 *)db,
-                       d->g2, d->chain, (u32)d->T, p);
+                       d->g2, d->chain, Ti, pi);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     (void)hipFree(dh); (void)hipFree(db);
@@ -333,20 +372,21 @@ extern "C" int bsgs_table_info(bsgs_dev *d, uint32_t *layout, uint64_t *device_b
 // ---- tiles ------------------------------------------------------------------------------------------------
 static void le_to_fe(fe &f, const uint8_t *le) { memcpy(f.v, le, 32); }
 
-static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq)
+static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq, int which)
 {
     TileArgs A;
-    A.g2 = d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.hitbuf = d->hitbuf;
-    A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->p; A.T = (u32)d->T;
+    hipStream_t st = which ? d->stream2 : d->stream;
+    A.g2 = d->g2; A.chain = d->chain + (which ? d->maxnonce * 2 * d->chain_tiles : 0); A.csr = d->csr; A.lines = d->lines; A.hitbuf = d->hitbuf;
+    A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     memset(A.centre, 0, sizeof A.centre);
     for (uint32_t k = 0; k < ntiles; k++) {
         le_to_fe(A.centre[2 * k], centres + (size_t)k * 64);
         le_to_fe(A.centre[2 * k + 1], centres + (size_t)k * 64 + 32);
     }
-    const dim3 grid((unsigned)(((d->T + 255) / 256) * ntiles)), block(256);
+    const dim3 grid((unsigned)(((d->Ti + 255) / 256) * ntiles)), block(256);
     const int var = d->variant;
-#define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, 0, d->stream, A)
+#define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, 0, st, A)
     switch (d->layout) {
     case BSGS_TABLE_LINES64:  if (var == 0) LAUNCH(2, 0); else if (var == 1) LAUNCH(2, 1); else LAUNCH(2, 2); break;
     case BSGS_TABLE_LINES128: if (var == 0) LAUNCH(3, 0); else if (var == 1) LAUNCH(3, 1); else LAUNCH(3, 2); break;
@@ -362,10 +402,18 @@ extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles
     if (!d || !centres) return fail(BSGS_ERR_ARG, "null");
     if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
     HIPCHK(hipSetDevice(d->id));
-    if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); d->timing_open = true; }
-    for (uint32_t k = 0; k < ntiles; k += d->tiles_per_launch) {
-        const uint32_t n = std::min<uint32_t>(d->tiles_per_launch, ntiles - k);
-        int rc = launch_tiles(d, centres + (size_t)k * 64, n, d->queued + k);
+    const uint32_t tpl = auto_tiles_per_launch(d);
+    int rcc = ensure_chain(d, tpl);
+    if (rcc) return rcc;
+    if (!d->timing_open) {
+        HIPCHK(hipEventRecord(d->ev0, d->stream));
+        HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0));     // stream2 starts after the timing origin (and after uploads)
+        d->timing_open = true;
+    }
+    for (uint32_t k = 0; k < ntiles; k += tpl) {
+        const uint32_t n = std::min<uint32_t>(tpl, ntiles - k);
+        const int which = d->nstreams == 2 ? (int)(d->launches & 1) : 0;
+        int rc = launch_tiles(d, centres + (size_t)k * 64, n, d->queued + k, which);
         if (rc) return rc;
         d->launches++;
     }
@@ -377,13 +425,23 @@ extern "C" int bsgs_collect(bsgs_dev *d, bsgs_hit_ex *hits, uint32_t max_hits, u
 {
     if (!d) return fail(BSGS_ERR_ARG, "null");
     HIPCHK(hipSetDevice(d->id));
-    if (d->timing_open) HIPCHK(hipEventRecord(d->ev1, d->stream));
+    if (d->timing_open) {
+        HIPCHK(hipEventRecord(d->ev1, d->stream));
+        HIPCHK(hipEventRecord(d->ev2, d->stream2));
+    }
+    HIPCHK(hipEventRecord(d->evj, d->stream2));                 // join: the read-back below follows both streams
+    HIPCHK(hipStreamWaitEvent(d->stream, d->evj, 0));
     HIPCHK(hipMemcpyAsync(d->hit_host, d->hitbuf, 64, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     uint32_t n = d->hit_host[0];
     if (kernel_ms) {
         *kernel_ms = 0.f;
-        if (d->timing_open) HIPCHK(hipEventElapsedTime(kernel_ms, d->ev0, d->ev1));
+        if (d->timing_open) {
+            float a = 0.f, b = 0.f;
+            HIPCHK(hipEventElapsedTime(&a, d->ev0, d->ev1));
+            HIPCHK(hipEventElapsedTime(&b, d->ev0, d->ev2));
+            *kernel_ms = a > b ? a : b;
+        }
     }
     d->timing_open = false;
     d->queued = 0;
@@ -460,7 +518,7 @@ extern "C" int bsgs_selftest_xs(bsgs_dev *d, const uint8_t px_le[32], const uint
     HIPCHK(hipMalloc(&dout, (size_t)count * 96));
     fe Px, Py;
     le_to_fe(Px, px_le); le_to_fe(Py, py_le);
-    hipLaunchKernelGGL(xs_selftest_kernel, dim3((count + 63) / 64), dim3(64), 0, d->stream, d->g2, (u32)d->T, d->p, Px, Py, first, count, dout);
+    hipLaunchKernelGGL(xs_selftest_kernel, dim3((count + 63) / 64), dim3(64), 0, d->stream, d->g2, d->Ti, d->pi, Px, Py, first, count, dout);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)count * 96, hipMemcpyDeviceToHost);
