@@ -1,0 +1,64 @@
+"""Multi-GPU plumbing shared by bench.py and the hosts: one process per GPU, replicated tables, tiles dealt
+round-robin, ONE start-up collective (table broadcast), none in steady state.  Backend "nccl" is RCCL over
+xGMI on the GPU box; the same code runs on "gloo" in the CPU tests (tests/test_dist_cpu.py)."""
+import os
+
+import torch
+import torch.distributed as td
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend, device=None):
+    rank, local_rank, world = env_world()
+    if world > 1 and not td.is_initialized():
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=device)
+        else:
+            td.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def deal_tiles(items, rank, world):
+    """the dispenser sequence (GetJob, 1_9_7File.pb:2077-2092) dealt statically: rank r takes r, r+N, ..."""
+    return items[rank::world]
+
+
+def broadcast_table(img, src=0):
+    """start-up broadcast of the htGPU image (a torch tensor on the rank's device); returns seconds spent"""
+    import time
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return 0.0
+    if img.is_cuda:
+        torch.cuda.synchronize()
+    t0 = time.time()
+    td.broadcast(img, src=src)
+    if img.is_cuda:
+        torch.cuda.synchronize()
+    return time.time() - t0
+
+
+def barrier(cuda=True):
+    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        td.barrier()
+    if cuda and torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def reduce_max(values, device="cpu"):
+    """max over ranks of a list of floats (wall time, kernel time)"""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return [float(x) for x in t]
+
+
+def reduce_sum_int(value, device="cpu"):
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return int(t[0])

@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: world_size 2 over gloo.  The distributed plumbing bench.py / the hosts use
+(pybsgs.dist: table broadcast, round-robin tile dealing, max / sum reductions) with the oracle's tile model
+standing in for the GPU engine.  The union of the ranks' hit lists must equal the single-process result and
+the throughput accounting must add up."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from pybsgs import dist as D
+import oracle_lib as O
+
+rank, local_rank, world = D.init("gloo")
+fx = json.load(open(os.path.join(ROOT, "tests", "golden", "small_w1024_ht8_t2_b2_p4.json")))
+gpu = bytes.fromhex(fx["htgpu"]); g2 = bytes.fromhex(fx["g2"])
+# rank 0 owns the table image; everyone else receives it through the one start-up collective
+img = torch.from_numpy(np.frombuffer(gpu, dtype=np.int32).copy()) if rank == 0 else torch.zeros(len(gpu) // 4, dtype=torch.int32)
+secs = D.broadcast_table(img, src=0)
+table = img.numpy().tobytes()
+assert table == gpu
+tiles = fx["tiles"] + fx["known_key"]["walk"]
+mine = D.deal_tiles(list(enumerate(tiles)), rank, world)
+hits = []
+for k, tl in mine:
+    h, n = O.tile_ref((int(tl["px"], 16), int(tl["py"], 16)), g2, fx["t"], fx["b"], fx["p"], table, fx["htsz"])
+    assert [list(x) for x in h] == tl["hits"]
+    hits += [(k, c, i) for c, i in h]
+D.barrier(cuda=False)
+steps = D.reduce_sum_int(len(mine) * 2 * fx["t"] * fx["b"] * fx["p"])
+tmax = D.reduce_max([0.5 + rank])[0]
+json.dump({"rank": rank, "world": world, "hits": hits, "tiles": [k for k, _ in mine], "steps": steps, "tmax": tmax},
+          open(os.path.join(OUT, "r%d.json" % rank), "w"))
+import torch.distributed as td
+td.destroy_process_group()
+'''
+
+
+def test_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text("ROOT = %r\nOUT = %r\n" % (ROOT, str(tmp_path)) + WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    r = [json.load(open(tmp_path / ("r%d.json" % k))) for k in range(2)]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "small_w1024_ht8_t2_b2_p4.json")))
+    tiles = fx["tiles"] + fx["known_key"]["walk"]
+    assert sorted(r[0]["tiles"] + r[1]["tiles"]) == list(range(len(tiles)))            # every tile exactly once
+    assert r[0]["tiles"] == list(range(0, len(tiles), 2)) and r[1]["tiles"] == list(range(1, len(tiles), 2))
+    union = sorted(tuple(h) for h in r[0]["hits"] + r[1]["hits"])
+    expect = sorted((k, c, i) for k, tl in enumerate(tiles) for c, i in tl["hits"])
+    assert union == expect
+    assert r[0]["steps"] == r[1]["steps"] == len(tiles) * 2 * fx["t"] * fx["b"] * fx["p"]
+    assert r[0]["tmax"] == r[1]["tmax"] == 1.5                                          # max over ranks
