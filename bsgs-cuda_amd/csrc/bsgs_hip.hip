@@ -1,8 +1,7 @@
 // bsgs_hip.hip -- C-ABI (include/bsgs_hip.h) of the MI355X giant-step engine: native API.
 // Build: see ../Makefile (hipcc --offload-arch=gfx950 -shared -fPIC).  No CPU fallback exists: every
 // entry point fails with BSGS_ERR_HIP when no gfx950 device / runtime is available.
-#include "giant_kernel.hip.h"
-#include "../../include/bsgs_hip.h"
+#include "bsgs_internal.h"
 #include "host_secp.h"
 
 #include <algorithm>
@@ -14,7 +13,7 @@
 #include <vector>
 
 static thread_local std::string g_err;
-static int fail(int code, const char *fmt, ...)
+int bsgs_fail(int code, const char *fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -24,44 +23,9 @@ static int fail(int code, const char *fmt, ...)
     g_err = buf;
     return code;
 }
-#define HIPCHK(x)                                                                                        \
-    do {                                                                                                 \
-        hipError_t e_ = (x);                                                                             \
-        if (e_ != hipSuccess) return fail(BSGS_ERR_HIP, "%s -> %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
 
 extern "C" const char *bsgs_last_error(void) { return g_err.c_str(); }
 extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
-
-struct bsgs_dev {
-    int id = 0;
-    hipStream_t stream = nullptr;          // main stream: uploads, relayouts, even launches
-    hipStream_t stream2 = nullptr;         // odd launches: the next launch's blocks fill the tail of the previous one
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, evj = nullptr;
-    int nstreams = 1;                      // 2 = alternate launches over two streams (BSGS_STREAMS=2; faster on average, noisier)
-    hipDeviceProp_t prop;
-    // geometry
-    uint32_t t = 0, b = 0, p = 0;          // the caller's geometry (file layout, hit index i = tid*p + j)
-    uint64_t T = 0, maxnonce = 0;
-    uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
-    uint64_t chain_tiles = 0;              // tiles the chain scratch is currently sized for
-    // buffers
-    u32x4 *g2 = nullptr;        // [p][4][T]
-    u32x4 *chain = nullptr;     // [stream][tile][p][2][T]
-    u32 *csr = nullptr;         // htGPU image
-    bool csr_owned = true;
-    u32x4 *lines = nullptr;
-    uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
-    uint32_t layout = 0;        // 1 csr, 2 lines64, 3 lines128
-    u32 *hitbuf = nullptr;      // device
-    u32 *hit_host = nullptr;    // pinned mirror
-    uint32_t max_hits = 1u << 16;
-    uint32_t queued = 0;
-    uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
-    uint64_t launches = 0;
-    int variant = 1;            // 0 synchronous probes, 1 pipelined probes, 2 + prefetched giants (BSGS_KERNEL_VARIANT)
-    bool timing_open = false;
-};
 
 static size_t hitbuf_bytes(const bsgs_dev *d) { return 64 + (size_t)d->max_hits * 16; }
 

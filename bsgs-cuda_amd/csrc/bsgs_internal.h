@@ -1,0 +1,44 @@
+// bsgs_internal.h -- private to libbsgs_hip.so: the device object shared by its translation units.
+#pragma once
+#include "giant_kernel.hip.h"
+#include "../../include/bsgs_hip.h"
+#include <string>
+
+int bsgs_fail(int code, const char *fmt, ...);
+#define HIPCHK(x)                                                                                        \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) return bsgs_fail(BSGS_ERR_HIP, "%s -> %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define fail bsgs_fail
+
+struct bsgs_dev {
+    int id = 0;
+    hipStream_t stream = nullptr;          // main stream: uploads, relayouts, even launches
+    hipStream_t stream2 = nullptr;         // odd launches: the next launch's blocks fill the tail of the previous one
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, evj = nullptr;
+    int nstreams = 1;                      // 2 = alternate launches over two streams (BSGS_STREAMS=2; faster on average, noisier)
+    hipDeviceProp_t prop;
+    // geometry
+    uint32_t t = 0, b = 0, p = 0;          // the caller's geometry (file layout, hit index i = tid*p + j)
+    uint64_t T = 0, maxnonce = 0;
+    uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
+    uint64_t chain_tiles = 0;              // tiles the chain scratch is currently sized for
+    // buffers
+    u32x4 *g2 = nullptr;        // [p][4][T]
+    u32x4 *chain = nullptr;     // [stream][tile][p][2][T]
+    u32 *csr = nullptr;         // htGPU image
+    bool csr_owned = true;
+    u32x4 *lines = nullptr;
+    uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
+    uint32_t layout = 0;        // 1 csr, 2 lines64, 3 lines128
+    u32 *hitbuf = nullptr;      // device
+    u32 *hit_host = nullptr;    // pinned mirror
+    uint32_t max_hits = 1u << 16;
+    uint32_t queued = 0;
+    uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
+    uint64_t launches = 0;
+    int variant = 1;            // 0 synchronous probes, 1 pipelined probes, 2 + prefetched giants (BSGS_KERNEL_VARIANT)
+    bool timing_open = false;
+};
+

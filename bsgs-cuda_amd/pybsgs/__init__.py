@@ -20,7 +20,7 @@ NATIVE_SYMBOLS = [
     "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
-    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count",
+    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -81,6 +81,8 @@ def lib():
             "bsgs_bench_modmul": [vp, C.POINTER(C.c_double)],
             "bsgs_set_tiles_per_launch": [vp, C.c_uint32],
             "bsgs_launch_count": [vp, C.POINTER(C.c_uint64)],
+            "bsgs_build_baby_tables": [vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32],
+            "bsgs_build_baby_tables_device": [vp, C.c_uint64, C.c_uint32, vp, vp],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -156,6 +158,18 @@ class Device:
 
     def upload_htgpu_device(self, dptr, ht_items, w, layout=TABLE_AUTO):
         _chk(self.L.bsgs_upload_htgpu_device(self.h, C.c_void_p(dptr), ht_items, w, layout))
+
+    def build_baby_tables(self, w, htsz, want_gpu=True, want_cpu=True, install_layout=0xFFFFFFFF):
+        items = 1 << htsz
+        g = C.create_string_buffer(4 * (items + 1) + 4 * w) if want_gpu else None
+        c = C.create_string_buffer(4 * (items + 1) + 8 * w) if want_cpu else None
+        _chk(self.L.bsgs_build_baby_tables(self.h, w, htsz, C.cast(g, C.c_void_p) if g else None,
+                                           C.cast(c, C.c_void_p) if c else None, install_layout))
+        return (g.raw if g else None), (c.raw if c else None)
+
+    def build_baby_tables_device(self, w, htsz, htgpu_dptr, htcpu_dptr=None):
+        _chk(self.L.bsgs_build_baby_tables_device(self.h, w, htsz, C.c_void_p(htgpu_dptr) if htgpu_dptr else None,
+                                                  C.c_void_p(htcpu_dptr) if htcpu_dptr else None))
 
     def table_info(self):
         lay, nb, ov = C.c_uint32(), C.c_uint64(), C.c_uint64()

@@ -95,6 +95,33 @@ def test_tile_x_coordinates_match_oracle(dev, O, small_fx):
             assert got[i] == (xm, xd if eq else xp, eq), (i, eq)
 
 
+def test_gpu_baby_table_builder(dev, O, small_fx):
+    """GPU builder (replaces GenBabys..packHTGPUFile, 197:1237-1328, 2555-2895, 3232-3444): byte-exact file images"""
+    import hashlib
+    import json
+    import os
+    fx = small_fx
+    gpu, cpu = dev.build_baby_tables(fx["w"], fx["htsz"])
+    assert gpu.hex() == fx["htgpu"] and cpu.hex() == fx["htcpu"]
+    # a size that is not a multiple of anything convenient, against the oracle's CPU builder
+    for w, htsz in ((70001, 13), (1 << 17, 16)):
+        rg, rc = O.build_baby_tables(w, htsz)
+        g, c = dev.build_baby_tables(w, htsz)
+        assert g == rg and c == rc, (w, htsz)
+    # BASELINE config 1 (-w 20 -htsz 18 onlygen): sha256 of the files from the plain-Python generator
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg1_digests.json")) as f:
+        d = json.load(f)
+    g, c = dev.build_baby_tables(d["w"], d["htsz"], install_layout=2)
+    assert hashlib.sha256(g).hexdigest() == d["htgpu_sha256"] and hashlib.sha256(c).hexdigest() == d["htcpu_sha256"]
+    assert dev.table_info()[0] == 2
+    # the installed table answers probes: k*G is found as code 5 for k <= w and not for k = w + 1
+    dev.upload_g2(bytes.fromhex(fx["g2"]), fx["t"], fx["b"], fx["p"])
+    for k, expect in ((1, True), (d["w"], True), (d["w"] + 1, False), (12345, True)):
+        P = O.pt_mul(k)
+        hits, _ = dev.step(P[0], P[1])
+        assert ((5, 0xFFFFFFFF) in hits) == expect, k
+
+
 # ------------------------------------------------------------------------------------------ tiles
 LAYOUTS = [1, 2, 3]      # CSR, 64-byte lines, 128-byte lines
 
