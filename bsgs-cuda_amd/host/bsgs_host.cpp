@@ -1,0 +1,505 @@
+// bsgs_host.cpp -- C++ host of the MI355X BSGS solver: the reference's `bsgscudaHT_1_9_6file.exe` command line,
+// file formats and outputs on top of libbsgs_hip.so's native API (include/bsgs_hip.h).
+//
+// Mirrors (file:line of /root/reference/1_9_7File.pb): flag parser getprogparam 875-1042 and the checks
+// 4412-4472, 4616-4630; start-up constants 4689-4712, 4759-4765; table files Save_HTpacked 3645-3759 /
+// Save_Load_Giants 1905-2058 (names and byte layouts kept; built on the GPU when missing); per-GPU driver
+// thread cuda() 2095-2553; tile dispenser GetJob 2077-2092; hit resolver checkerThread 3933-4296; checkpoint
+// saveCurentCNT 3897-3931 and its restore 4634-4686; per-pubkey loop, progress line and win.txt 4995-5168.
+// PureBasic is not available in this image, so the host is C++; INTEGRATION.md shows the PureBasic bindings.
+//
+// Build: make -C bsgs-cuda_amd host   ->  build/bsgs_mi355x
+#include "../../include/bsgs_hip.h"
+#include "../csrc/host_secp.h"
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+using hs::Affine;
+using hs::Scalar;
+
+// ---- SHA1 (configuration fingerprint of currentwork.txt, 1_9_7File.pb:4635-4636) -------------------------------
+static std::string sha1_hex(const std::string &msg)
+{
+    uint32_t h[5] = {0x67452301u, 0xEFCDAB89u, 0x98BADCFEu, 0x10325476u, 0xC3D2E1F0u};
+    std::string m = msg;
+    const uint64_t bits = (uint64_t)msg.size() * 8;
+    m.push_back((char)0x80);
+    while (m.size() % 64 != 56) m.push_back(0);
+    for (int i = 7; i >= 0; i--) m.push_back((char)(bits >> (8 * i)));
+    auto rol = [](uint32_t v, int s) { return (v << s) | (v >> (32 - s)); };
+    for (size_t off = 0; off < m.size(); off += 64) {
+        uint32_t w[80];
+        for (int i = 0; i < 16; i++)
+            w[i] = ((uint32_t)(uint8_t)m[off + 4 * i] << 24) | ((uint32_t)(uint8_t)m[off + 4 * i + 1] << 16) |
+                   ((uint32_t)(uint8_t)m[off + 4 * i + 2] << 8) | (uint32_t)(uint8_t)m[off + 4 * i + 3];
+        for (int i = 16; i < 80; i++) w[i] = rol(w[i - 3] ^ w[i - 8] ^ w[i - 14] ^ w[i - 16], 1);
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
+        for (int i = 0; i < 80; i++) {
+            uint32_t f, k;
+            if (i < 20) { f = (b & c) | (~b & d); k = 0x5A827999u; }
+            else if (i < 40) { f = b ^ c ^ d; k = 0x6ED9EBA1u; }
+            else if (i < 60) { f = (b & c) | (b & d) | (c & d); k = 0x8F1BBCDCu; }
+            else { f = b ^ c ^ d; k = 0xCA62C1D6u; }
+            const uint32_t t = rol(a, 5) + f + e + k + w[i];
+            e = d; d = c; c = rol(b, 30); b = a; a = t;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e;
+    }
+    char out[41];
+    snprintf(out, sizeof out, "%08x%08x%08x%08x%08x", h[0], h[1], h[2], h[3], h[4]);
+    return out;
+}
+
+// ---- configuration ---------------------------------------------------------------------------------------------------
+struct Config {
+    uint32_t t = 256, b = 132, p = 400;           // defaults 1_9_7File.pb:181-184
+    uint64_t w = 1ull << 25;
+    uint32_t htsz = 25;
+    std::string devices;                           // -d
+    std::string pub = "036d05521c67b9cc1c0ef906b42215c7120c7302c34d9316a2726199bedac50936";   // 1_9_7File.pb:191
+    std::string pk = "0x01", pke = "1ffffffffffffffff";                                        // 1_9_7File.pb:197, 210
+    bool pke_given = false;
+    std::string infile, recovery_file;
+    int wt = 180;
+    bool onlygen = false;                          // onlygen_1_9_6File0.exe behaviour: build files and exit
+    uint64_t max_tiles = 0;                        // test hook: stop after this many tiles (0 = unlimited)
+    std::string dir = ".";                         // where table / output files live
+};
+
+static void die(const std::string &msg)
+{
+    fprintf(stderr, "%s\n", msg.c_str());
+    exit(1);
+}
+static std::string cut_hex(std::string s)
+{
+    if (s.size() >= 2 && s[0] == '0' && (s[1] == 'x' || s[1] == 'X')) s = s.substr(2);
+    for (auto &c : s) c = (char)tolower(c);
+    return s;
+}
+
+static void usage(const Config &c)
+{
+    printf(" -t      Number of GPU threads, default %u\n -b      Number of GPU blocks, default %u\n -p      Number of pparam, default %u\n"
+           " -d      Select GPU IDs, default all\n-pb      Set single uncompressed/compressed pubkey for searching\n"
+           "-pk      Range start from , default %s\n-pke     End range \n-w       Set number of baby items 2^ or decimal representation\n"
+           "-htsz    Set number of HashTable 2^ , default %u\n-infile  Set file with pubkey for searching in uncompressed/compressed  format (search sequential)\n"
+           "-wl      Set recovery file from which the state will be loaded\n-wt      Set timer for autosaving current state, default every %dseconds\n"
+           "-onlygen Generate the table files and exit (onlygen_1_9_6File0.exe)\n-dir     Directory for table files, currentwork.txt and win.txt\n",
+           c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
+}
+
+static Config parse_args(int argc, char **argv)
+{
+    Config c;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        for (auto &ch : a) ch = (char)tolower(ch);
+        auto next = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
+        if (a == "-h") { usage(c); exit(0); }
+        else if (a == "-t") { c.t = (uint32_t)atoi(next().c_str()); printf("Number of GPU threads set to #%u\n", c.t); }
+        else if (a == "-b") { c.b = (uint32_t)atoi(next().c_str()); printf("Number of GPU blocks set to #%u\n", c.b); }
+        else if (a == "-p") { c.p = (uint32_t)atoi(next().c_str()); printf("Number of pparam set to #%u\n", c.p); }
+        else if (a == "-d") { c.devices = next(); printf("Used GPU devices #%s\n", c.devices.c_str()); }
+        else if (a == "-pb") { c.pub = cut_hex(next()); printf("Pubkey set to %s\n", c.pub.c_str()); }
+        else if (a == "-pk") { c.pk = cut_hex(next()); printf("Range begin: 0x%s\n", c.pk.c_str()); }
+        else if (a == "-pke") { c.pke = cut_hex(next()); c.pke_given = true; printf("Range end: 0x%s\n", c.pke.c_str()); }
+        else if (a == "-w") {                                   // <=32: 2^value (fractional allowed), else decimal  (1009-1022)
+            const std::string v = next();
+            const double d = atof(v.c_str());
+            if (d <= 32.0) { c.w = (uint64_t)std::pow(2.0, d); printf("Items number set to 2^%s=%llu\n", v.c_str(), (unsigned long long)c.w); }
+            else { c.w = strtoull(v.c_str(), nullptr, 10); printf("Items number set to %llu = 2^%f\n", (unsigned long long)c.w, std::log2((double)c.w)); }
+        }
+        else if (a == "-htsz") { c.htsz = (uint32_t)atoi(next().c_str()); printf("HT size set to 2^%u\n", c.htsz); }
+        else if (a == "-infile") { c.infile = next(); printf("Will be used file: %s\n", c.infile.c_str()); }
+        else if (a == "-wl") { c.recovery_file = next(); printf("Recovery work file: %s\n", c.recovery_file.c_str()); }
+        else if (a == "-wt") { c.wt = std::max(30, atoi(next().c_str())); printf("Saving timer every %d seconds\n", c.wt); }
+        else if (a == "-onlygen") c.onlygen = true;
+        else if (a == "-maxtiles") c.max_tiles = strtoull(next().c_str(), nullptr, 10);
+        else if (a == "-dir") c.dir = next();
+        else die("Unknown parameter " + a);
+    }
+    // limits 1_9_7File.pb:4412-4418, 4616-4618
+    if (c.w >= 3069485951ull) die("-w must be less than 3069485951");
+    if (c.htsz > 31 || c.htsz < 1) die("-htsz must be 1..31");
+    if (c.p & 1) die("-p must be even");
+    if (!c.t || !c.b || !c.p) die("-t -b -p must be non-zero");
+    return c;
+}
+
+// ---- files ---------------------------------------------------------------------------------------------------------------
+static bool read_file(const std::string &path, std::vector<uint8_t> &out, uint64_t expect)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) return false;
+    const uint64_t n = (uint64_t)f.tellg();
+    if (n != expect) return false;
+    out.resize(n);
+    f.seekg(0);
+    f.read((char *)out.data(), (std::streamsize)n);
+    return (bool)f;
+}
+static void write_file(const std::string &path, const void *p, uint64_t n)
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) die("Can`t create " + path);
+    f.write((const char *)p, (std::streamsize)n);
+}
+
+#define CK(call) do { int rc_ = (call); if (rc_ != BSGS_OK) die(std::string("error " #call "-") + std::to_string(rc_) + ": " + bsgs_last_error()); } while (0)
+
+// ---- shared state (the reference's globals *GlobKey / GlobPub / checker() / quit) ------------------------------
+struct Tile { Scalar key; Affine pub; };
+struct PendingHit { uint32_t code, idx; Tile tile; };
+
+struct Shared {
+    Config cfg;
+    uint64_t maxnonce = 0;
+    Scalar center_big, gstep, start, width;      // p*w ; 4*maxnonce*w ; -pk ; pke-pk
+    bool end_range = false;
+    Affine addpubg, center, pubadd, start_neg;   // -(2w)G ; -(p*w)G ; -(gstep)G ; -(start)G
+    Affine realpub, findpub;
+    std::mutex job_mutex;
+    Scalar glob_key;
+    Affine glob_pub;
+    std::mutex chk_mutex;
+    std::condition_variable chk_cv;
+    std::deque<PendingHit> checker;
+    std::atomic<bool> quit{false}, all_done{false};
+    std::atomic<uint64_t> steps_done{0}, tiles_done{0};
+    std::atomic<int> gpus_finished{0};
+    Scalar winkey;
+    bool found = false;
+    std::vector<uint8_t> htcpu;
+    int listpos = 1;
+    std::string mainpub_hex;
+};
+
+// GetJob for a batch: hand out `n` consecutive tiles (1_9_7File.pb:2077-2092), one normalisation for the batch
+static size_t get_jobs(Shared &S, size_t n, std::vector<Tile> &out)
+{
+    std::lock_guard<std::mutex> lk(S.job_mutex);
+    out.clear();
+    std::vector<hs::Jac> jac;
+    hs::Jac cur = hs::to_jac(S.glob_pub);
+    Scalar key = S.glob_key;
+    for (size_t i = 0; i < n; i++) {
+        if (S.end_range && hs::fe_cmp(key, S.width) > 0) break;              // 1_9_7File.pb:2512-2518
+        if (S.cfg.max_tiles && S.tiles_done.load() + out.size() >= S.cfg.max_tiles) break;
+        Tile t; t.key = key;
+        out.push_back(t);
+        jac.push_back(cur);
+        cur = hs::jac_add_affine(cur, S.pubadd);
+        key = hs::sc_add(key, S.gstep);
+    }
+    if (out.empty()) return 0;
+    jac.push_back(cur);
+    std::vector<Affine> aff = hs::batch_to_affine(jac);
+    for (size_t i = 0; i < out.size(); i++) out[i].pub = aff[i];
+    S.glob_pub = aff.back();
+    S.glob_key = key;
+    return out.size();
+}
+
+// ---- resolver: checkerThread 1_9_7File.pb:3933-4296 ---------------------------------------------------------------
+static int htcpu_lookup(const std::vector<uint8_t> &img, uint64_t ht_items, uint64_t key64, uint32_t *pos, int max)
+{
+    const uint32_t b = (uint32_t)key64 & (uint32_t)(ht_items - 1), h = (uint32_t)(key64 >> 32);
+    uint32_t lo, hi;
+    memcpy(&lo, &img[4 * (uint64_t)b], 4); memcpy(&hi, &img[4 * ((uint64_t)b + 1)], 4);
+    const uint8_t *items = img.data() + 4 * (ht_items + 1);
+    int n = 0;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t v; memcpy(&v, items + 8 * (uint64_t)k, 4);
+        if (v == h) { if (n < max) memcpy(&pos[n], items + 8 * (uint64_t)k + 4, 4); n++; }
+    }
+    return n;
+}
+
+static bool try_key(const Shared &S, const Scalar &kprime, Scalar &key_out)
+{
+    const Affine tp = hs::point_mul(hs::G, kprime);
+    if (tp.inf || !hs::fe_equal(tp.x, S.findpub.x) || !hs::fe_equal(tp.y, S.findpub.y)) return false;
+    const Scalar key = hs::sc_add(kprime, S.start);
+    const Affine rp = hs::point_mul(hs::G, key);
+    if (rp.inf || !hs::fe_equal(rp.x, S.realpub.x) || !hs::fe_equal(rp.y, S.realpub.y)) return false;
+    key_out = key;
+    return true;
+}
+
+static bool resolve_hit(const Shared &S, const PendingHit &hit, Scalar &key_out)
+{
+    // k' = cnt + C + e1*(idx+1)*2w + e2*b'   (all sign pairs are verified by scalar multiplication)
+    const Scalar base = hs::sc_add(hit.tile.key, S.center_big);
+    const Scalar two_w = hs::sc_from_u128((hs::u128)S.cfg.w * 2);
+    const Scalar g = hit.code == 5 ? hs::fe_from_u64(0) : hs::sc_mul_small(two_w, (uint64_t)hit.idx + 1);
+    if (hit.code == 4) {
+        Scalar k = hs::sc_add(base, g); if (try_key(S, k, key_out)) return true;
+        k = hs::sc_sub(base, g); return try_key(S, k, key_out);
+    }
+    Affine T = hit.tile.pub;
+    if (hit.code != 5) {
+        Affine gi = hs::point_mul(S.addpubg, hs::fe_from_u64((uint64_t)hit.idx + 1));
+        if (hit.code == 2) gi = hs::affine_neg(gi);
+        T = hs::point_add(hit.tile.pub, gi);
+        if (T.inf) return false;
+    }
+    uint32_t pos[64];
+    int np = htcpu_lookup(S.htcpu, 1ull << S.cfg.htsz, T.x.l[0], pos, 64);
+    if (np > 64) np = 64;
+    for (int q = 0; q < np; q++) {
+        const Scalar bb = hs::fe_from_u64((uint64_t)pos[q] + 1);
+        for (int s1 = 0; s1 < 2; s1++) {
+            Scalar e1g;
+            if (hit.code == 5) { if (s1) break; e1g = base; }
+            else e1g = ((hit.code == 1) ^ (s1 == 1)) ? hs::sc_add(base, g) : hs::sc_sub(base, g);
+            Scalar k = hs::sc_add(e1g, bb); if (try_key(S, k, key_out)) return true;
+            k = hs::sc_sub(e1g, bb); if (try_key(S, k, key_out)) return true;
+        }
+    }
+    return false;
+}
+
+static void checker_thread(Shared *S)
+{
+    for (;;) {
+        PendingHit hit;
+        {
+            std::unique_lock<std::mutex> lk(S->chk_mutex);
+            S->chk_cv.wait(lk, [&] { return !S->checker.empty() || S->all_done.load(); });
+            if (S->checker.empty()) return;
+            hit = S->checker.front();
+            S->checker.pop_front();
+        }
+        if (S->quit.load()) continue;
+        Scalar key;
+        if (resolve_hit(*S, hit, key)) {
+            S->winkey = key; S->found = true;
+            S->quit.store(true);
+        }
+    }
+}
+
+// ---- per-GPU driver thread: cuda() 1_9_7File.pb:2095-2553 ---------------------------------------------------------
+static void gpu_thread(Shared *S, int gpu, const std::vector<uint8_t> *htgpu, const std::vector<uint8_t> *g2)
+{
+    bsgs_dev *dev = nullptr;
+    CK(bsgs_dev_open(gpu, &dev));
+    char name[256];
+    CK(bsgs_dev_name(dev, name, sizeof name));
+    uint64_t fr = 0, tot = 0;
+    CK(bsgs_dev_meminfo(dev, &fr, &tot));
+    printf("GPU #%d %s memory %.0f/%.0f MB\n", gpu, name, fr / 1048576.0, tot / 1048576.0);
+    CK(bsgs_upload_g2(dev, g2->data(), S->cfg.t, S->cfg.b, S->cfg.p));
+    CK(bsgs_upload_htgpu(dev, htgpu->data(), 1ull << S->cfg.htsz, S->cfg.w, BSGS_TABLE_AUTO));
+    const size_t batch = 64;
+    std::vector<Tile> tiles;
+    std::vector<uint8_t> centres;
+    std::vector<bsgs_hit_ex> hits(65536);
+    while (!S->quit.load()) {
+        const size_t n = get_jobs(*S, batch, tiles);
+        if (!n) break;                                            // end of space for this GPU
+        centres.resize(n * 64);
+        for (size_t i = 0; i < n; i++) hs::affine_to_le(tiles[i].pub, &centres[i * 64], &centres[i * 64 + 32]);
+        uint32_t nh = 0;
+        int rc = bsgs_run(dev, centres.data(), (uint32_t)n, hits.data(), (uint32_t)hits.size(), &nh, nullptr);
+        if (rc != BSGS_OK && rc != BSGS_ERR_OVERFLOW) die(std::string("error bsgs_run-") + std::to_string(rc) + ": " + bsgs_last_error());
+        if (nh) {
+            std::lock_guard<std::mutex> lk(S->chk_mutex);
+            for (uint32_t i = 0; i < std::min<uint32_t>(nh, (uint32_t)hits.size()); i++)
+                S->checker.push_back({hits[i].code, hits[i].idx, tiles[hits[i].tile]});
+            S->chk_cv.notify_all();
+        }
+        S->steps_done += 2 * S->maxnonce * n;
+        S->tiles_done += n;
+    }
+    bsgs_dev_close(dev);
+    printf("GPU#%d job finished\n", gpu);
+    S->gpus_finished++;
+}
+
+// ---- checkpoint: saveCurentCNT 1_9_7File.pb:3897-3931 ------------------------------------------------------------
+static std::string fingerprint(const Config &c)
+{
+    std::ostringstream s;
+    s << c.t << c.b << c.p << c.w << c.pk << c.pke << c.htsz;     // Str(t)+Str(b)+Str(p)+Str(w)+pk+pke+Str(htsz)  (4635-4636)
+    return sha1_hex(s.str());
+}
+static void save_checkpoint(Shared &S)
+{
+    Scalar cnt;
+    { std::lock_guard<std::mutex> lk(S.job_mutex); cnt = S.glob_key; }
+    // the dispenser's next counter minus the tiles possibly still in flight would be exact; like the reference we
+    // store a counter that has certainly been handed out, restart re-does at most the in-flight batch
+    const std::string tmp = S.cfg.dir + "/currentwork.temp", dst = S.cfg.dir + "/currentwork.txt";
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        f << S.listpos << "\r\n" << S.mainpub_hex << "\r\n" << hs::fe_to_hex(cnt) << "\r\n" << fingerprint(S.cfg) << "\r\n";
+    }
+    rename(tmp.c_str(), dst.c_str());
+}
+
+int main(int argc, char **argv)
+{
+    printf("BSGS MI355X (drop-in for bsgscudaHT 1.9.7-file0) on %s\n", bsgs_version());
+    Shared S;
+    S.cfg = parse_args(argc, argv);
+    const Config &c = S.cfg;
+    int ngpu = 0;
+    CK(bsgs_dev_count(&ngpu));
+    if (ngpu <= 0) die("No GPU found");
+    std::vector<int> gpus;
+    if (c.devices.empty()) for (int i = 0; i < ngpu; i++) gpus.push_back(i);
+    else { std::stringstream ss(c.devices); std::string tok; while (std::getline(ss, tok, ',')) gpus.push_back(atoi(tok.c_str())); }
+
+    S.maxnonce = (uint64_t)c.t * c.b * c.p;
+    // constants (1_9_7File.pb:4689-4712, 4759-4765)
+    const Scalar two_w = hs::sc_from_u128((hs::u128)c.w * 2);
+    S.addpubg = hs::affine_neg(hs::point_mul(hs::G, two_w));
+    printf("GiantSUBvalue:%s\nGiantSUBpubkey: %s\n", hs::fe_to_hex(two_w).c_str(), hs::compress_pubkey(S.addpubg).c_str());
+    S.center_big = hs::sc_from_u128((hs::u128)c.p * c.w);
+    S.center = hs::affine_neg(hs::point_mul(hs::G, S.center_big));
+    S.gstep = hs::sc_mul_small(hs::sc_from_u128((hs::u128)S.maxnonce * c.w), 4);
+    S.pubadd = hs::affine_neg(hs::point_mul(hs::G, S.gstep));
+    printf("Gstep: %s\n", hs::fe_to_hex(S.gstep).c_str());
+
+    // ---- table files (Save_HTpacked 3645-3759, Save_Load_Giants 1905-2058): load, or build on the GPU and save
+    const uint64_t ht_items = 1ull << c.htsz;
+    const std::string gxhex = hs::fe_to_hex(hs::G.x);
+    const std::string stem = c.dir + "/" + gxhex + "_" + std::to_string(c.w) + "_" + std::to_string(ht_items);
+    const std::string f_gpu = stem + "_htGPUv0.BIN", f_cpu = stem + "_htCPUv0.BIN";
+    const std::string f_g2 = c.dir + "/" + std::to_string(c.t) + "_" + std::to_string(c.b) + "_" + std::to_string(c.p) + "_" + std::to_string(c.w) + "_g2.BIN";
+    std::vector<uint8_t> htgpu, g2;
+    const uint64_t gpu_bytes = 4 * (ht_items + 1) + 4 * c.w, cpu_bytes = 4 * (ht_items + 1) + 8 * c.w, g2_bytes = 64 * S.maxnonce;
+    bsgs_dev *d0 = nullptr;
+    auto dev0 = [&]() { if (!d0) CK(bsgs_dev_open(gpus[0], &d0)); return d0; };
+    if (read_file(f_gpu, htgpu, gpu_bytes) && read_file(f_cpu, S.htcpu, cpu_bytes)) printf("Both HT files exist\n");
+    else {
+        printf("Generate HT with %llu items on the GPU\n", (unsigned long long)c.w);
+        const auto t0 = std::chrono::steady_clock::now();
+        htgpu.resize(gpu_bytes); S.htcpu.resize(cpu_bytes);
+        CK(bsgs_build_baby_tables(dev0(), c.w, c.htsz, htgpu.data(), S.htcpu.data(), BSGS_NO_INSTALL));
+        write_file(f_cpu, S.htcpu.data(), cpu_bytes);
+        write_file(f_gpu, htgpu.data(), gpu_bytes);
+        printf("Done in %.1fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    if (read_file(f_g2, g2, g2_bytes)) printf("Load BIN file:%s\n", f_g2.c_str());
+    else {
+        printf("Generate Giants Buffer: %llu items\n", (unsigned long long)S.maxnonce);
+        uint8_t axy[64];
+        hs::affine_to_le(S.addpubg, axy, axy + 32);
+        CK(bsgs_generate_g2(dev0(), axy, c.t, c.b, c.p));
+        g2.resize(g2_bytes);
+        CK(bsgs_download_g2(dev0(), g2.data(), g2_bytes));
+        write_file(f_g2, g2.data(), g2_bytes);
+        printf("Save BIN file:%s\n", f_g2.c_str());
+    }
+    if (d0) { bsgs_dev_close(d0); d0 = nullptr; }
+    if (c.onlygen) { printf("onlygen: files ready\n"); return 0; }
+
+    // ---- range (1_9_7File.pb:4887-4943)
+    if (!hs::fe_from_hex(S.start, c.pk) || hs::fe_is_zero(S.start)) die("Start range can`t be zero");
+    printf("START RANGE= %s\n", hs::fe_to_hex(S.start).c_str());
+    if (c.pke_given) {
+        Scalar e;
+        if (!hs::fe_from_hex(e, c.pke) || hs::fe_cmp(e, S.start) <= 0) die("End range should be more than begin range!");
+        S.width = hs::sc_sub(e, S.start); S.end_range = true;
+        printf("  END RANGE= %s\nWIDTH RANGE= %s\n", hs::fe_to_hex(e).c_str(), hs::fe_to_hex(S.width).c_str());
+    }
+    S.start_neg = hs::affine_neg(hs::point_mul(hs::G, S.start));
+
+    // ---- recovery (-wl, 1_9_7File.pb:4634-4686)
+    bool recovery = false; int rec_pos = 0; std::string rec_pub, rec_cnt;
+    if (!c.recovery_file.empty()) {
+        std::ifstream f(c.recovery_file);
+        std::string l1, l2, l3, l4;
+        auto strip = [](std::string s) { while (!s.empty() && (s.back() == '\r' || s.back() == '\n')) s.pop_back(); return s; };
+        if (!std::getline(f, l1) || !std::getline(f, l2) || !std::getline(f, l3) || !std::getline(f, l4)) die("Can`t read recovery file");
+        if (strip(l4) != fingerprint(c)) die("Recovery file was made with other settings");
+        rec_pos = atoi(strip(l1).c_str()); rec_pub = strip(l2); rec_cnt = strip(l3); recovery = true;
+        printf("Recovery: listpos %d counter %s\n", rec_pos, rec_cnt.c_str());
+    } else remove((c.dir + "/win.txt").c_str());                      // 1_9_7File.pb:4959-4963
+
+    // ---- public keys (-pb or -infile, one per line, searched sequentially: 4370-4385, 4995-5168)
+    std::vector<std::string> pubs;
+    if (!c.infile.empty()) {
+        std::ifstream f(c.infile);
+        if (!f) die("Can`t open " + c.infile);
+        std::string line;
+        while (std::getline(f, line)) { while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back(); if (!line.empty()) pubs.push_back(cut_hex(line)); }
+    } else pubs.push_back(c.pub);
+
+    int finditems = 0;
+    for (size_t li = 0; li < pubs.size(); li++) {
+        S.listpos = (int)li + 1;
+        if (recovery && S.listpos != rec_pos) continue;
+        if (!hs::parse_pubkey(S.realpub, pubs[li]) || !hs::on_curve(S.realpub)) die("Invalid Public Key (-pb) length!!!");
+        S.mainpub_hex = hs::fe_to_hex(S.realpub.x) + hs::fe_to_hex(S.realpub.y);
+        if (recovery && S.mainpub_hex != rec_pub) die("Find position but the keys are different");
+        printf("\nFindpubkey  : %s\n", hs::compress_pubkey(S.realpub).c_str());
+        S.findpub = hs::point_add(S.realpub, S.start_neg);             // 1_9_7File.pb:5042
+        printf("Searchpubkey: %s\n", hs::compress_pubkey(S.findpub).c_str());
+        // dispenser seed (1_9_7File.pb:5046-5064)
+        S.glob_key = hs::fe_from_u64(1);
+        if (recovery) { if (!hs::fe_from_hex(S.glob_key, rec_cnt)) die("bad counter"); recovery = false; }
+        S.glob_pub = hs::point_add(hs::point_add(S.findpub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
+        S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        Scalar one = hs::fe_from_u64(1), two = hs::fe_from_u64(2);
+        Scalar trivial;                                                 // keys 1 and 2 are answered without search (5069-5107)
+        bool is_trivial = false;
+        for (const Scalar &k : {one, two}) { const Affine q = hs::point_mul(hs::G, k); if (hs::fe_equal(q.x, S.realpub.x) && hs::fe_equal(q.y, S.realpub.y)) { trivial = k; is_trivial = true; } }
+        if (!is_trivial) {
+            std::thread chk(checker_thread, &S);
+            std::vector<std::thread> th;
+            for (int g : gpus) th.emplace_back(gpu_thread, &S, g, &htgpu, &g2);
+            auto last_save = std::chrono::steady_clock::now();
+            uint64_t last_steps = 0; auto last_t = t0;
+            while (S.gpus_finished.load() < (int)gpus.size()) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(200));
+                const auto now = std::chrono::steady_clock::now();
+                if (std::chrono::duration<double>(now - last_t).count() >= 2.0) {       // progress line 5119-5142
+                    const uint64_t st = S.steps_done.load();
+                    const double rate = (st - last_steps) / std::chrono::duration<double>(now - last_t).count();
+                    Scalar cnt; { std::lock_guard<std::mutex> lk(S.job_mutex); cnt = S.glob_key; }
+                    printf("\rCnt:%s [%d] = %.0f MKeys/s x2^%.2f=2^%.2f   ", hs::fe_to_hex(cnt).c_str() + 40, (int)gpus.size(), rate / 1048576.0,
+                           std::log2(2.0 * c.w), rate > 0 ? std::log2(rate * 2.0 * c.w) : 0.0);
+                    fflush(stdout);
+                    last_steps = st; last_t = now;
+                }
+                if (std::chrono::duration<double>(now - last_save).count() >= c.wt) { save_checkpoint(S); last_save = now; }
+            }
+            for (auto &x : th) x.join();
+            // drain the checker queue, then stop it
+            for (;;) { { std::lock_guard<std::mutex> lk(S.chk_mutex); if (S.checker.empty()) break; } if (S.quit.load()) break; std::this_thread::sleep_for(std::chrono::milliseconds(10)); }
+            S.all_done = true; S.chk_cv.notify_all();
+            chk.join();
+        } else { S.winkey = trivial; S.found = true; }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (S.found) {                                                  // win.txt 1_9_7File.pb:5146-5160
+            const std::string head = "KEY[" + std::to_string(S.listpos) + "]: ";
+            const std::string l1 = head + "0x" + hs::fe_to_hex(S.winkey);
+            const std::string l2 = std::string(head.size() - 5, ' ') + "Pub: " + hs::compress_pubkey(S.realpub);
+            printf("\n****************************\n%s\n%s\n****************************\n", l1.c_str(), l2.c_str());
+            std::ofstream f(c.dir + "/win.txt", std::ios::app | std::ios::binary);
+            f << l1 << "\r\n" << l2 << "\r\n";
+            finditems++;
+        } else printf("\nReached end of space\n");
+        printf("Job time %.1fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)S.tiles_done.load(), (double)S.steps_done.load());
+    }
+    printf("Found %d of %zu\n", finditems, pubs.size());
+    return 0;
+}

@@ -1,0 +1,94 @@
+"""GPU end-to-end tests of the C++ host (bsgs-cuda_amd/host/bsgs_host.cpp): the reference's command line,
+file formats and outputs, with the reference's own known-key vectors (1_9_7File.pb:189, 191, 200-203)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "bsgs-cuda_amd", "build", "bsgs_mi355x")
+
+PUB_1E9AD = ("e1e5e6f7b0b8d67604e3940c87bf06b814cedc486112b9956c68e3d78b1bd812"
+             "97fe4f65fbd6e9f7eb1eea80b144d1487f2a9b0aeae5fcf6f43b41491641884e")
+PUB_65BIT = "036d05521c67b9cc1c0ef906b42215c7120c7302c34d9316a2726199bedac50936"
+PUB_PUZZLE64 = "03100611c54dfef604163b8358f7b7fac13ce478e02cb224ae16d45526b25d9d4d"
+
+
+def run(args, cwd, timeout=600):
+    assert os.path.exists(EXE), "host binary missing: run __graft_entry__.build()"
+    res = subprocess.run([EXE, "-dir", str(cwd)] + args, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    return res.stdout
+
+
+def win_lines(cwd):
+    with open(os.path.join(cwd, "win.txt"), "rb") as f:
+        return f.read().decode().split("\r\n")
+
+
+def test_onlygen_config1_files(tmp_path):
+    """BASELINE config 1: onlygen -w 20 -htsz 18 -> reference-named files, byte-exact (sha256 from the plain-Python generator)"""
+    with open(os.path.join(ROOT, "tests", "golden", "cfg1_digests.json")) as f:
+        d = json.load(f)
+    run(["-onlygen", "-t", str(d["g2_t"]), "-b", str(d["g2_b"]), "-p", str(d["g2_p"]), "-w", "20", "-htsz", "18"], tmp_path)
+    for name, size, sha in ((d["htgpu_name"], d["htgpu_size"], d["htgpu_sha256"]), (d["htcpu_name"], d["htcpu_size"], d["htcpu_sha256"]),
+                            (d["g2_name"], d["g2_size"], d["g2_sha256"])):
+        blob = open(os.path.join(tmp_path, name), "rb").read()
+        assert len(blob) == size and hashlib.sha256(blob).hexdigest() == sha, name
+    # second run loads the files instead of regenerating them
+    out = run(["-onlygen", "-t", str(d["g2_t"]), "-b", str(d["g2_b"]), "-p", str(d["g2_p"]), "-w", "20", "-htsz", "18"], tmp_path)
+    assert "Both HT files exist" in out and "Load BIN file" in out
+
+
+def test_key_1e9ad(tmp_path):
+    out = run(["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14", "-pb", PUB_1E9AD, "-pk", "1"], tmp_path)
+    lines = win_lines(tmp_path)
+    assert lines[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
+    assert lines[1].endswith("Pub: 02" + PUB_1E9AD[:64]) and lines[1].startswith(" " * 3)
+    assert "KEY[1]" in out
+
+
+def test_key_65bit_default_range_and_puzzle64(tmp_path):
+    """the reference's default job (1_9_7File.pb:191, 197, 210) and the puzzle-64 vector (200-203)"""
+    geo = ["-t", "256", "-b", "64", "-p", "256", "-w", "26", "-htsz", "24"]
+    run(geo + ["-pb", PUB_65BIT], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x16f7027bbf8454a5c
+    out = run(geo + ["-pb", PUB_PUZZLE64, "-pk", "8000000000000000", "-pke", "ffffffffffffffff"], tmp_path)
+    assert "Both HT files exist" in out                                  # tables were reused from the first run
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0xf7051f27b09112d4
+
+
+def test_infile_sequential_and_recovery(tmp_path):
+    """-infile: several keys searched one after the other; -wl: resume from a currentwork.txt (4 CRLF lines,
+    SHA1 configuration fingerprint, 1_9_7File.pb:3911-3917, 4635-4686)"""
+    import oracle_lib as O
+    keys = [0x1E9AD, 2, 0x7A5B3C]
+    pubs = []
+    for k in keys:
+        x, y = O.pt_mul(k)
+        pubs.append("%064x%064x" % (x, y))
+    infile = tmp_path / "pubs.txt"
+    infile.write_text("\n".join(pubs) + "\n")
+    geo = ["-t", "64", "-b", "4", "-p", "8", "-w", "14", "-htsz", "12"]
+    run(geo + ["-infile", str(infile), "-pk", "1"], tmp_path)
+    lines = win_lines(tmp_path)
+    assert [lines[0], lines[2], lines[4]] == ["KEY[%d]: 0x%064x" % (i + 1, k) for i, k in enumerate(keys)]
+    # recovery: position 3, counter just below the tile that holds the key
+    t, b, p, w, htsz = 64, 4, 8, 1 << 14, 12
+    gstep = 4 * t * b * p * w
+    cnt = 1 + (max(0, (keys[2] - 1) // gstep - 1)) * gstep
+    fp = hashlib.sha1(("%d%d%d%d%s%s%d" % (t, b, p, w, "1", "1ffffffffffffffff", htsz)).encode()).hexdigest()
+    rec = tmp_path / "currentwork.txt"
+    rec.write_bytes(("3\r\n%s\r\n%064x\r\n%s\r\n" % (pubs[2], cnt, fp)).encode())
+    os.remove(tmp_path / "win.txt")
+    out = run(geo + ["-infile", str(infile), "-pk", "1", "-wl", str(rec)], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[3]: 0x%064x" % keys[2]
+    assert "Recovery: listpos 3" in out
+    # a fingerprint made with other settings is refused
+    rec.write_bytes(("3\r\n%s\r\n%064x\r\n%s\r\n" % (pubs[2], cnt, "0" * 40)).encode())
+    res = subprocess.run([EXE, "-dir", str(tmp_path)] + geo + ["-infile", str(infile), "-pk", "1", "-wl", str(rec)], capture_output=True, text=True)
+    assert res.returncode != 0
