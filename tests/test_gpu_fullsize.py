@@ -1,0 +1,65 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties (GPU):
+  * config 2 (-t 256 -b 256 -p 256 -w 26 -htsz 25) and the metric's -w 30 -htsz 28 table, REAL tables and giants;
+  * tiles whose centre is m*G for crafted m: the analytic hit list {(1,i): m-(i+1)2w in +-[1,w]} u {(2,i): m+(i+1)2w in
+    +-[1,w]} u {(5,-): |m| <= w} must be reported, at the first / middle / last giant index;
+  * every reported hit beyond the analytic ones must be a genuine 32-bit hash collision: the exact CSR layout and the
+    bucket-line layout must return identical lists (two independent probe implementations over the same table)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+def analytic_hits(m, w, maxnonce):
+    hits = []
+    if 1 <= abs(m) <= w:
+        hits.append((5, 0xFFFFFFFF))
+    for code, sgn in ((1, -1), (2, +1)):                 # P + G2[i] = (m - (i+1)2w)G ; P - G2[i] = (m + (i+1)2w)G
+        # |m + sgn*(i+1)*2w| in [1, w]
+        centre = -sgn * m                                # (i+1)*2w close to centre
+        for i1 in {centre // (2 * w), centre // (2 * w) + 1}:
+            if 1 <= i1 <= maxnonce and 1 <= abs(m + sgn * i1 * 2 * w) <= w:
+                hits.append((code, i1 - 1))
+    return sorted(set(hits), key=lambda h: (h[1], h[0]))
+
+
+@pytest.mark.parametrize("wexp,htsz", [(26, 25), (30, 28)])
+def test_fullsize_planted_and_layout_agreement(wexp, htsz):
+    import pybsgs
+    from pybsgs import ecpy
+    t, b, p, w = 256, 256, 256, 1 << wexp
+    maxnonce = t * b * p
+    dev = pybsgs.Device(0)
+    img = torch.empty((1 << htsz) + 1 + w, dtype=torch.int32, device="cuda:0")
+    dev.build_baby_tables_device(w, htsz, img.data_ptr())
+    A = ecpy.addpubg(w)
+    dev.generate_g2(A[0], A[1], t, b, p)
+    ms = [(0 + 1) * 2 * w + 77,                       # code 1 at the first giant
+          -((maxnonce) * 2 * w) + 12345,              # code 2 at the last giant
+          (maxnonce // 2) * 2 * w - w,                # edge b' = w: two adjacent giants see it (code 1)
+          w // 3,                                     # code 5 (P itself is a baby point)
+          -(5000001 * 2 * w) - 1,                     # code 2, b' = 1
+          (maxnonce + 5) * 2 * w + 99,                # beyond the last giant: nothing
+          3 * 2 * w * 1000003 + (w - 7)]
+    centres = [ecpy.mul(m % N) for m in ms]
+    results = {}
+    for layout in (pybsgs.TABLE_LINES64, pybsgs.TABLE_CSR):
+        dev.upload_htgpu_device(img.data_ptr(), 1 << htsz, w, layout)
+        assert dev.table_info()[0] == layout
+        hits, n, _ = dev.run(centres, 65536)
+        assert n == len(hits)
+        results[layout] = hits
+    assert results[pybsgs.TABLE_LINES64] == results[pybsgs.TABLE_CSR]          # two probe implementations, one answer
+    got = results[pybsgs.TABLE_LINES64]
+    extra = 0
+    for k, m in enumerate(ms):
+        mine = [(c, i) for tile, c, i in got if tile == k]
+        expect = analytic_hits(m, w, maxnonce)
+        assert set(expect) <= set(mine), (k, expect, mine)
+        extra += len(mine) - len(expect)
+    # 32-bit hash collisions: ~ 2 * maxnonce * (w / 2^htsz) / 2^32 per tile  (0.016 at -w 26, 0.03 at -w 30)
+    assert extra <= 3
+    assert ms[5] and not analytic_hits(ms[5], w, maxnonce)
+    dev.close()
