@@ -53,6 +53,8 @@ extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
     HIPCHK(hipEventCreate(&d->ev1));
     HIPCHK(hipEventCreate(&d->ev2));
     HIPCHK(hipEventCreateWithFlags(&d->evj, hipEventDisableTiming));
+    if (const char *v = getenv("BSGS_DEBUG_PHASES")) d->debug_flags = (unsigned)atoi(v);     // timing experiments only
+    if (const char *v = getenv("BSGS_BLOCK")) { int bsz = atoi(v); if (bsz == 64 || bsz == 128 || bsz == 256) d->block_size = (unsigned)bsz; }
     if (const char *v = getenv("BSGS_STREAMS")) d->nstreams = atoi(v) == 2 ? 2 : 1;     // tuning / A-B only
     HIPCHK(hipMalloc(&d->hitbuf, hitbuf_bytes(d)));
     HIPCHK(hipHostMalloc(&d->hit_host, hitbuf_bytes(d), hipHostMallocDefault));
@@ -343,12 +345,14 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
     A.g2 = d->g2; A.chain = d->chain + (which ? d->maxnonce * 2 * d->chain_tiles : 0); A.csr = d->csr; A.lines = d->lines; A.hitbuf = d->hitbuf;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
+    A.debug_flags = d->debug_flags; A.pad0 = 0;
     memset(A.centre, 0, sizeof A.centre);
     for (uint32_t k = 0; k < ntiles; k++) {
         le_to_fe(A.centre[2 * k], centres + (size_t)k * 64);
         le_to_fe(A.centre[2 * k + 1], centres + (size_t)k * 64 + 32);
     }
-    const dim3 grid((unsigned)(((d->Ti + 255) / 256) * ntiles)), block(256);
+    const unsigned bs = d->block_size;
+    const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
     const int var = d->variant;
 #define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, 0, st, A)
     switch (d->layout) {

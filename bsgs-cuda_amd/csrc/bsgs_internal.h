@@ -17,6 +17,8 @@ struct bsgs_dev {
     hipStream_t stream = nullptr;          // main stream: uploads, relayouts, even launches
     hipStream_t stream2 = nullptr;         // odd launches: the next launch's blocks fill the tail of the previous one
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, evj = nullptr;
+    unsigned debug_flags = 0;
+    unsigned block_size = 256;             // threads per workgroup of the tile kernel (BSGS_BLOCK: 64/128/256)
     int nstreams = 1;                      // 2 = alternate launches over two streams (BSGS_STREAMS=2; faster on average, noisier)
     hipDeviceProp_t prop;
     // geometry
