@@ -27,6 +27,7 @@ int bsgs_fail(int code, const char *fmt, ...)
 extern "C" const char *bsgs_last_error(void) { return g_err.c_str(); }
 extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
 
+static void release_pending(bsgs_dev *d);
 static size_t hitbuf_bytes(const bsgs_dev *d) { return 64 + (size_t)d->max_hits * 16; }
 
 extern "C" int bsgs_dev_count(int *n)
@@ -74,7 +75,8 @@ static void free_g2(bsgs_dev *d)
 {
     if (d->g2) (void)hipFree(d->g2);
     if (d->chain) (void)hipFree(d->chain);
-    d->g2 = nullptr; d->chain = nullptr;
+    if (d->schain) (void)hipFree(d->schain);
+    d->g2 = nullptr; d->chain = nullptr; d->schain = nullptr; d->schain_blocks = 0;
 }
 
 extern "C" int bsgs_dev_close(bsgs_dev *d)
@@ -82,6 +84,7 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     if (!d) return BSGS_OK;
     (void)hipSetDevice(d->id);
     (void)hipStreamSynchronize(d->stream);
+    release_pending(d);
     free_table(d); free_g2(d);
     if (d->hitbuf) (void)hipFree(d->hitbuf);
     if (d->hit_host) (void)hipHostFree(d->hit_host);
@@ -353,7 +356,7 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
     }
     const unsigned bs = d->block_size;
     const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
-    const int var = d->variant;
+    const int var = d->variant >= 3 ? 1 : d->variant;
 #define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, 0, st, A)
     switch (d->layout) {
     case BSGS_TABLE_LINES64:  if (var == 0) LAUNCH(2, 0); else if (var == 1) LAUNCH(2, 1); else LAUNCH(2, 2); break;
@@ -365,11 +368,77 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
     return BSGS_OK;
 }
 
+static void release_pending(bsgs_dev *d)
+{
+    for (void *p : d->pending_dev) (void)hipFree(p);
+    for (void *p : d->pending_pinned) (void)hipHostFree(p);
+    d->pending_dev.clear(); d->pending_pinned.clear();
+}
+
+// one launch for the whole batch: every resident block walks a sequence of tiles (giant_stream_kernel)
+static int launch_stream(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq)
+{
+    const unsigned bs = d->block_size;
+    const uint32_t nb = (uint32_t)((d->Ti + bs - 1) / bs);
+    int per_cu = 0;
+    const bool l128 = d->layout == BSGS_TABLE_LINES128;
+    const bool ldsp = d->variant == 4, full = d->variant == 5;
+    const size_t lds_bytes = full ? (size_t)(bs / 64) * (6144 + (l128 ? 8192 : 4096)) : ldsp ? (size_t)(bs / 64) * (l128 ? 8192 : 4096) : 0;
+    const void *fn = full ? (l128 ? (const void *)giant_stream_lds_kernel<3> : (const void *)giant_stream_lds_kernel<2>)
+                   : l128 ? (ldsp ? (const void *)giant_stream_kernel<3, true> : (const void *)giant_stream_kernel<3, false>)
+                          : (ldsp ? (const void *)giant_stream_kernel<2, true> : (const void *)giant_stream_kernel<2, false>);
+    if (lds_bytes > 65536) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)bs, lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t resident = (uint64_t)per_cu * d->prop.multiProcessorCount;
+    uint32_t ng = (uint32_t)std::max<uint64_t>(1, resident / nb);
+    if (d->tiles_per_launch) ng = d->tiles_per_launch;            // explicit override (A-B experiments)
+    ng = std::min(ng, ntiles);
+    const uint64_t blocks = (uint64_t)nb * ng;
+    if (d->schain_blocks < blocks) {
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (d->schain) (void)hipFree(d->schain);
+        d->schain = nullptr; d->schain_blocks = 0;
+        HIPCHK(hipMalloc(&d->schain, blocks * d->pi * 2 * bs * 16));
+        d->schain_blocks = blocks;
+    }
+    void *pin = nullptr, *dc = nullptr;
+    HIPCHK(hipHostMalloc(&pin, (size_t)ntiles * 64, hipHostMallocDefault));
+    d->pending_pinned.push_back(pin);
+    memcpy(pin, centres, (size_t)ntiles * 64);
+    HIPCHK(hipMalloc(&dc, (size_t)ntiles * 64));
+    d->pending_dev.push_back(dc);
+    HIPCHK(hipMemcpyAsync(dc, pin, (size_t)ntiles * 64, hipMemcpyHostToDevice, d->stream));
+    StreamArgs S;
+    S.g2 = d->g2; S.chain = d->schain; S.csr = d->csr; S.lines = d->lines; S.hitbuf = d->hitbuf; S.centres = (const fe *)dc;
+    S.ht_items = d->ht_items; S.ht_mask = (u32)(d->ht_items - 1); S.pparam = d->pi; S.T = d->Ti; S.max_hits = d->max_hits;
+    S.tile_seq = seq; S.ntiles = ntiles; S.ngroups = ng; S.debug_flags = d->debug_flags;
+    const dim3 grid((unsigned)blocks), block(bs);
+    if (full) { if (l128) hipLaunchKernelGGL((giant_stream_lds_kernel<3>), grid, block, lds_bytes, d->stream, S);
+                else      hipLaunchKernelGGL((giant_stream_lds_kernel<2>), grid, block, lds_bytes, d->stream, S); }
+    else if (l128) { if (ldsp) hipLaunchKernelGGL((giant_stream_kernel<3, true>), grid, block, lds_bytes, d->stream, S);
+                else      hipLaunchKernelGGL((giant_stream_kernel<3, false>), grid, block, 0, d->stream, S); }
+    else      { if (ldsp) hipLaunchKernelGGL((giant_stream_kernel<2, true>), grid, block, lds_bytes, d->stream, S);
+                else      hipLaunchKernelGGL((giant_stream_kernel<2, false>), grid, block, 0, d->stream, S); }
+    HIPCHK(hipGetLastError());
+    return BSGS_OK;
+}
+
 extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
 {
     if (!d || !centres) return fail(BSGS_ERR_ARG, "null");
     if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
     HIPCHK(hipSetDevice(d->id));
+    const bool streamed = (d->variant >= 3 && d->variant <= 5) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
+    if (streamed) {
+        if (!ntiles) return BSGS_OK;
+        if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0)); d->timing_open = true; }
+        int rcs = launch_stream(d, centres, ntiles, d->queued);
+        if (rcs) return rcs;
+        d->launches++;
+        d->queued += ntiles;
+        return BSGS_OK;
+    }
     const uint32_t tpl = auto_tiles_per_launch(d);
     int rcc = ensure_chain(d, tpl);
     if (rcc) return rcc;
@@ -413,6 +482,7 @@ extern "C" int bsgs_collect(bsgs_dev *d, bsgs_hit_ex *hits, uint32_t max_hits, u
     }
     d->timing_open = false;
     d->queued = 0;
+    release_pending(d);
     const uint32_t stored = std::min(n, d->max_hits);
     if (stored) {
         HIPCHK(hipMemcpyAsync(d->hit_host + BSGS_HIT_HEADER_WORDS, d->hitbuf + BSGS_HIT_HEADER_WORDS, (size_t)stored * 16,
@@ -455,6 +525,28 @@ extern "C" int bsgs_step(bsgs_dev *d, const uint8_t px_le[32], const uint8_t py_
     if (rc && rc != BSGS_ERR_OVERFLOW) return rc;
     const uint32_t m = std::min(n, max_hits);
     for (uint32_t i = 0; i < m && hits; i++) { hits[i].code = ex[i].code; hits[i].idx = ex[i].idx; }
+    return rc;
+}
+
+// ---- phase timing: the same batch run with the kernel stopping after phase 1, after phase 2, and in full ------
+extern "C" int bsgs_profile_phases(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, float ms_out[3])
+{
+    if (!d || !centres || !ms_out) return fail(BSGS_ERR_ARG, "null");
+    const unsigned saved_flags = d->debug_flags;
+    const int saved_variant = d->variant;
+    if (d->variant >= 3) d->variant = 1;                       // the per-tile kernel has separable phases
+    const unsigned flags[3] = {1u, 2u, 0u};
+    int rc = BSGS_OK;
+    for (int k = 0; k < 3 && rc == BSGS_OK; k++) {
+        d->debug_flags = flags[k];
+        for (int rep = 0; rep < 2 && rc == BSGS_OK; rep++) {   // first repetition warms up
+            uint32_t nh = 0;
+            rc = bsgs_run(d, centres, ntiles, nullptr, 0, &nh, &ms_out[k]);
+            if (rc == BSGS_ERR_OVERFLOW) rc = BSGS_OK;
+        }
+    }
+    d->debug_flags = saved_flags;
+    d->variant = saved_variant;
     return rc;
 }
 

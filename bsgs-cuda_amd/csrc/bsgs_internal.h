@@ -3,6 +3,7 @@
 #include "giant_kernel.hip.h"
 #include "../../include/bsgs_hip.h"
 #include <string>
+#include <vector>
 
 int bsgs_fail(int code, const char *fmt, ...);
 #define HIPCHK(x)                                                                                        \
@@ -26,6 +27,9 @@ struct bsgs_dev {
     uint64_t T = 0, maxnonce = 0;
     uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
     uint64_t chain_tiles = 0;              // tiles the chain scratch is currently sized for
+    u32x4 *schain = nullptr;               // streamed kernel: one scratch slot per resident block
+    uint64_t schain_blocks = 0;
+    std::vector<void *> pending_dev, pending_pinned;   // per-enqueue centre buffers, released by bsgs_collect
     // buffers
     u32x4 *g2 = nullptr;        // [p][4][T]
     u32x4 *chain = nullptr;     // [stream][tile][p][2][T]
@@ -40,7 +44,7 @@ struct bsgs_dev {
     uint32_t queued = 0;
     uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
     uint64_t launches = 0;
-    int variant = 1;            // 0 synchronous probes, 1 pipelined probes, 2 + prefetched giants (BSGS_KERNEL_VARIANT)
+    int variant = 1;            // 3 streamed ping-pong kernel (default) ; per-tile kernels: 0 synchronous probes, 1 pipelined probes, 2 + prefetched giants (BSGS_KERNEL_VARIANT)
     bool timing_open = false;
 };
 

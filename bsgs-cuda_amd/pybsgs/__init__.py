@@ -20,7 +20,7 @@ NATIVE_SYMBOLS = [
     "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
-    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device",
+    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_profile_phases",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -83,6 +83,7 @@ def lib():
             "bsgs_launch_count": [vp, C.POINTER(C.c_uint64)],
             "bsgs_build_baby_tables": [vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32],
             "bsgs_build_baby_tables_device": [vp, C.c_uint64, C.c_uint32, vp, vp],
+            "bsgs_profile_phases": [vp, u8p, C.c_uint32, C.POINTER(C.c_float)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -236,6 +237,11 @@ class Device:
             v = [int.from_bytes(out.raw[96 * k + 32 * i:96 * k + 32 * i + 32], "little") for i in range(3)]
             r.append((v[0], v[1], v[2] & 1))
         return r
+
+    def profile_phases(self, blob, ntiles):
+        ms = (C.c_float * 3)()
+        _chk(self.L.bsgs_profile_phases(self.h, blob, ntiles, ms))
+        return [float(x) for x in ms]
 
     def bench_random_read(self, footprint_bytes, granule=64):
         g, r = C.c_double(), C.c_double()
