@@ -300,3 +300,38 @@ def test_cuda_compat_layer_runs_a_tile(small_fx):
         assert [list(h) for h in got] == tl["hits"], tl["kind"]
     assert L.cuMemFree_v2(base.value) == 0
     assert L.cuCtxDestroy_v2(ctx) == 0
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("streams", [1, 2])
+def test_all_kernel_variants_agree_with_oracle(O, small_fx, variant, streams):
+    """every kernel variant (per-tile 0-2, streamed 3-5; one or two HIP streams) returns the oracle's hit lists:
+    many tiles per call, so the streamed kernels walk sequences in both directions"""
+    import os
+    import pybsgs
+    if streams == 2 and variant >= 3:
+        pytest.skip("streamed kernels use one launch per batch")
+    os.environ["BSGS_KERNEL_VARIANT"], os.environ["BSGS_STREAMS"] = str(variant), str(streams)
+    try:
+        d = pybsgs.Device(0)
+    finally:
+        del os.environ["BSGS_KERNEL_VARIANT"], os.environ["BSGS_STREAMS"]
+    t, b, p, w, htsz = 64, 8, 12, 1 << 16, 14                       # T = 512: two 256-thread slices
+    g2, gpu, centres = _planted_case(O, 4242, t, b, p, w, htsz, 12, 9)
+    centres = centres + [O.pt_mul(k) for k in (5, 70000)] + [O.g2_unpack(g2, t, b, p, 77)]     # code 5 twice, an x-equal tile
+    d.upload_g2(g2, t, b, p)
+    d.upload_htgpu(gpu, 1 << htsz, w, 2)
+    hits, n, _ = d.run(centres, 65536)
+    ref_all = []
+    for k, Pt in enumerate(centres):
+        r, _ = O.tile_ref(Pt, g2, t, b, p, gpu, htsz, 0, 65536)
+        ref_all += [(k, c, i) for c, i in r]
+    assert n == len(ref_all) and hits == ref_all
+    # fixture tiles one at a time (sequence length 1)
+    fx = small_fx
+    d.upload_g2(bytes.fromhex(fx["g2"]), fx["t"], fx["b"], fx["p"])
+    d.upload_htgpu(bytes.fromhex(fx["htgpu"]), 1 << fx["htsz"], fx["w"], 3)
+    for tl in fx["tiles"]:
+        h, _ = d.step(int(tl["px"], 16), int(tl["py"], 16))
+        assert [list(x) for x in h] == tl["hits"]
+    d.close()
