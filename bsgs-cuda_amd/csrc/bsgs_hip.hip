@@ -356,6 +356,12 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
     }
     const unsigned bs = d->block_size;
     const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
+    if (d->variant == 6 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+        if (d->layout == BSGS_TABLE_LINES64) hipLaunchKernelGGL(giant_pair_kernel<2>, grid, block, 0, st, A);
+        else                                 hipLaunchKernelGGL(giant_pair_kernel<3>, grid, block, 0, st, A);
+        HIPCHK(hipGetLastError());
+        return BSGS_OK;
+    }
     const int var = d->variant >= 3 ? 1 : d->variant;
 #define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, 0, st, A)
     switch (d->layout) {

@@ -331,6 +331,27 @@ static void gpu_thread(Shared *S, int gpu, const std::vector<uint8_t> *htgpu, co
     S->gpus_finished++;
 }
 
+// ---- Tune (1_9_7File.pb:324-431 prints suggested -t -b -p -w -htsz per GPU from free memory and SM count) ----------
+// MI355X version: the engine re-batches internally, so -t/-b/-p only set the tile size; -w / -htsz follow from HBM:
+// device bytes = 64*2^htsz (bucket lines) + 4*2^htsz + 4*w (htGPU image) + 64*t*b*p (giants) + chain scratch (~8 GiB).
+static void tune(int gpu)
+{
+    bsgs_dev *dev = nullptr;
+    if (bsgs_dev_open(gpu, &dev) != BSGS_OK) return;
+    uint64_t fr = 0, tot = 0;
+    int cus = 0;
+    char name[256] = "";
+    bsgs_dev_meminfo(dev, &fr, &tot); bsgs_dev_cu_count(dev, &cus); bsgs_dev_name(dev, name, sizeof name);
+    const uint64_t budget = fr > (24ull << 30) ? fr - (24ull << 30) : fr / 2;      // giants, chain scratch, hit buffers, slack
+    uint32_t htsz = 20;
+    while (htsz < 31 && (68ull << (htsz + 1)) + (16ull << (htsz + 1)) <= budget) htsz++;     // lines + image at 4 entries per bucket
+    double wl = htsz + 2.0;                                                          // mean bucket load 4
+    const double wmax = std::log2(3069485950.0);                                     // reference format limit (1_9_7File.pb:4412-4418)
+    if (wl > wmax) wl = wmax;
+    printf("GPU #%d %s: %d CUs, %.0f MB free -> suggested  -t 256 -b 256 -p 256 -w %.2f -htsz %u\n", gpu, name, cus, fr / 1048576.0, wl, htsz);
+    bsgs_dev_close(dev);
+}
+
 // ---- checkpoint: saveCurentCNT 1_9_7File.pb:3897-3931 ------------------------------------------------------------
 static std::string fingerprint(const Config &c)
 {
@@ -365,6 +386,7 @@ int main(int argc, char **argv)
     if (c.devices.empty()) for (int i = 0; i < ngpu; i++) gpus.push_back(i);
     else { std::stringstream ss(c.devices); std::string tok; while (std::getline(ss, tok, ',')) gpus.push_back(atoi(tok.c_str())); }
 
+    for (int g : gpus) tune(g);
     S.maxnonce = (uint64_t)c.t * c.b * c.p;
     // constants (1_9_7File.pb:4689-4712, 4759-4765)
     const Scalar two_w = hs::sc_from_u128((hs::u128)c.w * 2);
