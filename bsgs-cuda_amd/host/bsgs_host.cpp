@@ -181,6 +181,9 @@ struct Shared {
     std::atomic<bool> quit{false}, all_done{false};
     std::atomic<uint64_t> steps_done{0}, tiles_done{0};
     std::atomic<int> gpus_finished{0};
+    std::mutex inflight_mutex;
+    std::vector<Scalar> inflight;                 // per GPU: counter of the oldest tile it has not finished (checkpoint = min, 1_9_7File.pb:3904-3911)
+    std::vector<bool> inflight_valid;
     Scalar winkey;
     bool found = false;
     std::vector<uint8_t> htcpu;
@@ -294,7 +297,7 @@ static void checker_thread(Shared *S)
 }
 
 // ---- per-GPU driver thread: cuda() 1_9_7File.pb:2095-2553 ---------------------------------------------------------
-static void gpu_thread(Shared *S, int gpu, const std::vector<uint8_t> *htgpu, const std::vector<uint8_t> *g2)
+static void gpu_thread(Shared *S, int gpu, int slot, const std::vector<uint8_t> *htgpu, const std::vector<uint8_t> *g2)
 {
     bsgs_dev *dev = nullptr;
     CK(bsgs_dev_open(gpu, &dev));
@@ -311,6 +314,7 @@ static void gpu_thread(Shared *S, int gpu, const std::vector<uint8_t> *htgpu, co
     std::vector<bsgs_hit_ex> hits(65536);
     while (!S->quit.load()) {
         const size_t n = get_jobs(*S, batch, tiles);
+        { std::lock_guard<std::mutex> lk(S->inflight_mutex); S->inflight_valid[slot] = n > 0; if (n) S->inflight[slot] = tiles[0].key; }
         if (!n) break;                                            // end of space for this GPU
         centres.resize(n * 64);
         for (size_t i = 0; i < n; i++) hs::affine_to_le(tiles[i].pub, &centres[i * 64], &centres[i * 64 + 32]);
@@ -326,6 +330,7 @@ static void gpu_thread(Shared *S, int gpu, const std::vector<uint8_t> *htgpu, co
         S->steps_done += 2 * S->maxnonce * n;
         S->tiles_done += n;
     }
+    { std::lock_guard<std::mutex> lk(S->inflight_mutex); S->inflight_valid[slot] = false; }
     bsgs_dev_close(dev);
     printf("GPU#%d job finished\n", gpu);
     S->gpus_finished++;
@@ -361,10 +366,11 @@ static std::string fingerprint(const Config &c)
 }
 static void save_checkpoint(Shared &S)
 {
+    // the minimum counter over the GPUs' unfinished batches (a restart re-does at most the batches in flight)
     Scalar cnt;
     { std::lock_guard<std::mutex> lk(S.job_mutex); cnt = S.glob_key; }
-    // the dispenser's next counter minus the tiles possibly still in flight would be exact; like the reference we
-    // store a counter that has certainly been handed out, restart re-does at most the in-flight batch
+    { std::lock_guard<std::mutex> lk(S.inflight_mutex);
+      for (size_t g = 0; g < S.inflight.size(); g++) if (S.inflight_valid[g] && hs::fe_cmp(S.inflight[g], cnt) < 0) cnt = S.inflight[g]; }
     const std::string tmp = S.cfg.dir + "/currentwork.temp", dst = S.cfg.dir + "/currentwork.txt";
     {
         std::ofstream f(tmp, std::ios::binary);
@@ -487,7 +493,8 @@ int main(int argc, char **argv)
         if (!is_trivial) {
             std::thread chk(checker_thread, &S);
             std::vector<std::thread> th;
-            for (int g : gpus) th.emplace_back(gpu_thread, &S, g, &htgpu, &g2);
+            S.inflight.assign(gpus.size(), hs::fe_from_u64(0)); S.inflight_valid.assign(gpus.size(), false);
+            for (size_t gi = 0; gi < gpus.size(); gi++) th.emplace_back(gpu_thread, &S, gpus[gi], (int)gi, &htgpu, &g2);
             auto last_save = std::chrono::steady_clock::now();
             uint64_t last_steps = 0; auto last_t = t0;
             while (S.gpus_finished.load() < (int)gpus.size()) {
