@@ -362,11 +362,21 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
         HIPCHK(hipGetLastError());
         return BSGS_OK;
     }
-    const int var = d->variant >= 3 ? 1 : d->variant;
-#define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, 0, st, A)
+    if (d->variant == 9 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+        const bool l128 = d->layout == BSGS_TABLE_LINES128;
+        const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
+        const bool dbg = d->debug_flags != 0 || d->phase_probe;
+        if (l128) { if (dbg) hipLaunchKernelGGL((giant_tile2_kernel<3, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_tile2_kernel<3, false>), grid, block, lds, st, A); }
+        else      { if (dbg) hipLaunchKernelGGL((giant_tile2_kernel<2, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_tile2_kernel<2, false>), grid, block, lds, st, A); }
+        HIPCHK(hipGetLastError());
+        return BSGS_OK;
+    }
+    const int var = (d->variant == 7 || d->variant == 8) ? d->variant : d->variant >= 3 ? 1 : d->variant;
+    const size_t lds8 = var == 8 ? (size_t)(bs / 64) * (d->layout == BSGS_TABLE_LINES128 ? 8192 : 4096) : 0;
+#define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, (V == 8 ? lds8 : 0), st, A)
     switch (d->layout) {
-    case BSGS_TABLE_LINES64:  if (var == 0) LAUNCH(2, 0); else if (var == 1) LAUNCH(2, 1); else LAUNCH(2, 2); break;
-    case BSGS_TABLE_LINES128: if (var == 0) LAUNCH(3, 0); else if (var == 1) LAUNCH(3, 1); else LAUNCH(3, 2); break;
+    case BSGS_TABLE_LINES64:  if (var == 0) LAUNCH(2, 0); else if (var == 1) LAUNCH(2, 1); else if (var == 7) LAUNCH(2, 7); else if (var == 8) LAUNCH(2, 8); else LAUNCH(2, 2); break;
+    case BSGS_TABLE_LINES128: if (var == 0) LAUNCH(3, 0); else if (var == 1) LAUNCH(3, 1); else if (var == 7) LAUNCH(3, 7); else if (var == 8) LAUNCH(3, 8); else LAUNCH(3, 2); break;
     default:                  LAUNCH(0, 0); break;
     }
 #undef LAUNCH
@@ -540,9 +550,10 @@ extern "C" int bsgs_profile_phases(bsgs_dev *d, const uint8_t *centres, uint32_t
     if (!d || !centres || !ms_out) return fail(BSGS_ERR_ARG, "null");
     const unsigned saved_flags = d->debug_flags;
     const int saved_variant = d->variant;
-    if (d->variant >= 3) d->variant = 1;                       // the per-tile kernel has separable phases
+    if (d->variant >= 3 && d->variant <= 5) d->variant = 9;    // the per-tile kernels have separable phases
     const unsigned flags[3] = {1u, 2u, 0u};
     int rc = BSGS_OK;
+    d->phase_probe = true;
     for (int k = 0; k < 3 && rc == BSGS_OK; k++) {
         d->debug_flags = flags[k];
         for (int rep = 0; rep < 2 && rc == BSGS_OK; rep++) {   // first repetition warms up
@@ -553,6 +564,7 @@ extern "C" int bsgs_profile_phases(bsgs_dev *d, const uint8_t *centres, uint32_t
     }
     d->debug_flags = saved_flags;
     d->variant = saved_variant;
+    d->phase_probe = false;
     return rc;
 }
 

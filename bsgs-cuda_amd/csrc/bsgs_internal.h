@@ -19,6 +19,7 @@ struct bsgs_dev {
     hipStream_t stream2 = nullptr;         // odd launches: the next launch's blocks fill the tail of the previous one
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, evj = nullptr;
     unsigned debug_flags = 0;
+    bool phase_probe = false;
     unsigned block_size = 256;             // threads per workgroup of the tile kernel (BSGS_BLOCK: 64/128/256)
     int nstreams = 1;                      // 2 = alternate launches over two streams (BSGS_STREAMS=2; faster on average, noisier)
     hipDeviceProp_t prop;
@@ -44,7 +45,9 @@ struct bsgs_dev {
     uint32_t queued = 0;
     uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
     uint64_t launches = 0;
-    int variant = 1;            // 3 streamed ping-pong kernel (default) ; per-tile kernels: 0 synchronous probes, 1 pipelined probes, 2 + prefetched giants (BSGS_KERNEL_VARIANT)
+    int variant = 9;            // BSGS_KERNEL_VARIANT (all bit-identical): per-tile kernels 0 synchronous probes, 1 pipelined probes,
+                                // 2 early / 7 late prefetch, 8 = 7 + LDS-staged probe, 9 = both probes LDS-staged (default), 6 pair-batched
+                                // chain; streamed ping-pong kernels 3, 4 (LDS probes), 5 (all loads LDS-staged, counted vmcnt)
     bool timing_open = false;
 };
 

@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(PKG_ROOT, "build", "libbsgs_hip.so")
+LIB_PATH = os.environ.get("BSGS_LIB_PATH") or os.path.join(PKG_ROOT, "build", "libbsgs_hip.so")   # override: A/B of alternative builds
 
 TABLE_AUTO, TABLE_CSR, TABLE_LINES64, TABLE_LINES128 = 0, 1, 2, 3
 ERR_OVERFLOW = -5
