@@ -297,7 +297,8 @@ static void checker_thread(Shared *S)
 }
 
 // ---- per-GPU driver thread: cuda() 1_9_7File.pb:2095-2553 ---------------------------------------------------------
-static void gpu_thread(Shared *S, int gpu, int slot, const std::vector<uint8_t> *htgpu, const std::vector<uint8_t> *g2)
+// devices are opened and loaded once (1_9_7File.pb:2181-2357) and serve every public key of the run
+static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8_t> &htgpu, const std::vector<uint8_t> &g2)
 {
     bsgs_dev *dev = nullptr;
     CK(bsgs_dev_open(gpu, &dev));
@@ -306,8 +307,13 @@ static void gpu_thread(Shared *S, int gpu, int slot, const std::vector<uint8_t> 
     uint64_t fr = 0, tot = 0;
     CK(bsgs_dev_meminfo(dev, &fr, &tot));
     printf("GPU #%d %s memory %.0f/%.0f MB\n", gpu, name, fr / 1048576.0, tot / 1048576.0);
-    CK(bsgs_upload_g2(dev, g2->data(), S->cfg.t, S->cfg.b, S->cfg.p));
-    CK(bsgs_upload_htgpu(dev, htgpu->data(), 1ull << S->cfg.htsz, S->cfg.w, BSGS_TABLE_AUTO));
+    CK(bsgs_upload_g2(dev, g2.data(), S.cfg.t, S.cfg.b, S.cfg.p));
+    CK(bsgs_upload_htgpu(dev, htgpu.data(), 1ull << S.cfg.htsz, S.cfg.w, BSGS_TABLE_AUTO));
+    return dev;
+}
+
+static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
+{
     const size_t batch = 64;
     std::vector<Tile> tiles;
     std::vector<uint8_t> centres;
@@ -331,7 +337,6 @@ static void gpu_thread(Shared *S, int gpu, int slot, const std::vector<uint8_t> 
         S->tiles_done += n;
     }
     { std::lock_guard<std::mutex> lk(S->inflight_mutex); S->inflight_valid[slot] = false; }
-    bsgs_dev_close(dev);
     printf("GPU#%d job finished\n", gpu);
     S->gpus_finished++;
 }
@@ -470,6 +475,11 @@ int main(int argc, char **argv)
         while (std::getline(f, line)) { while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back(); if (!line.empty()) pubs.push_back(cut_hex(line)); }
     } else pubs.push_back(c.pub);
 
+    std::vector<bsgs_dev *> devs;
+    for (int g : gpus) devs.push_back(open_and_load(S, g, htgpu, g2));
+    std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
+    std::vector<uint8_t>().swap(g2);
+
     int finditems = 0;
     for (size_t li = 0; li < pubs.size(); li++) {
         S.listpos = (int)li + 1;
@@ -494,7 +504,7 @@ int main(int argc, char **argv)
             std::thread chk(checker_thread, &S);
             std::vector<std::thread> th;
             S.inflight.assign(gpus.size(), hs::fe_from_u64(0)); S.inflight_valid.assign(gpus.size(), false);
-            for (size_t gi = 0; gi < gpus.size(); gi++) th.emplace_back(gpu_thread, &S, gpus[gi], (int)gi, &htgpu, &g2);
+            for (size_t gi = 0; gi < gpus.size(); gi++) th.emplace_back(gpu_thread, &S, gpus[gi], (int)gi, devs[gi]);
             auto last_save = std::chrono::steady_clock::now();
             uint64_t last_steps = 0; auto last_t = t0;
             while (S.gpus_finished.load() < (int)gpus.size()) {
@@ -529,6 +539,7 @@ int main(int argc, char **argv)
         } else printf("\nReached end of space\n");
         printf("Job time %.1fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)S.tiles_done.load(), (double)S.steps_done.load());
     }
+    for (bsgs_dev *d : devs) bsgs_dev_close(d);
     printf("Found %d of %zu\n", finditems, pubs.size());
     return 0;
 }

@@ -92,3 +92,23 @@ def test_infile_sequential_and_recovery(tmp_path):
     rec.write_bytes(("3\r\n%s\r\n%064x\r\n%s\r\n" % (pubs[2], cnt, "0" * 40)).encode())
     res = subprocess.run([EXE, "-dir", str(tmp_path)] + geo + ["-infile", str(infile), "-pk", "1", "-wl", str(rec)], capture_output=True, text=True)
     assert res.returncode != 0
+
+
+def test_config4_style_many_keys_64bit_range(tmp_path):
+    """BASELINE config 4 in small: -infile with 16 public keys searched sequentially over the fixed 64-bit range
+    8000000000000000..ffffffffffffffff (devices are loaded once, the dispenser is re-seeded per key)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    keys, st = [], 0xC0FFEE
+    for _ in range(16):
+        st, r = ecpy.splitmix64(st)
+        keys.append((1 << 63) + (r >> 1))
+    infile = tmp_path / "pubs.txt"
+    infile.write_text("\n".join("%064x%064x" % ecpy.mul(k) for k in keys) + "\n")
+    out = run(["-t", "256", "-b", "128", "-p", "256", "-w", "28", "-htsz", "26", "-infile", str(infile),
+               "-pk", "8000000000000000", "-pke", "ffffffffffffffff"], tmp_path)
+    lines = win_lines(tmp_path)
+    got = [int(l.split("0x")[1], 16) for l in lines if l.startswith("KEY[")]
+    assert got == keys
+    assert out.count("memory") == 1                                      # one device, opened and loaded once
