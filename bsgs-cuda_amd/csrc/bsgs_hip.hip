@@ -362,7 +362,16 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
         HIPCHK(hipGetLastError());
         return BSGS_OK;
     }
-    if (d->variant == 9 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+    if (d->variant == 10 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+        const bool l128 = d->layout == BSGS_TABLE_LINES128;
+        const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
+        const bool dbg = d->debug_flags != 0 || d->phase_probe;
+        if (l128) { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<3, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<3, false>), grid, block, lds, st, A); }
+        else      { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<2, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<2, false>), grid, block, lds, st, A); }
+        HIPCHK(hipGetLastError());
+        return BSGS_OK;
+    }
+    if ((d->variant == 9 || d->variant == 10) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         const bool l128 = d->layout == BSGS_TABLE_LINES128;
         const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
         const bool dbg = d->debug_flags != 0 || d->phase_probe;

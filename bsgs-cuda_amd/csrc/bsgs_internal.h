@@ -45,9 +45,10 @@ struct bsgs_dev {
     uint32_t queued = 0;
     uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
     uint64_t launches = 0;
-    int variant = 9;            // BSGS_KERNEL_VARIANT (all bit-identical): per-tile kernels 0 synchronous probes, 1 pipelined probes,
-                                // 2 early / 7 late prefetch, 8 = 7 + LDS-staged probe, 9 = both probes LDS-staged (default), 6 pair-batched
-                                // chain; streamed ping-pong kernels 3, 4 (LDS probes), 5 (all loads LDS-staged, counted vmcnt)
+    int variant = 10;           // BSGS_KERNEL_VARIANT (all bit-identical): per-tile kernels 0 synchronous probes, 1 pipelined probes,
+                                // 2 early / 7 late prefetch, 8 = 7 + LDS-staged probe, 9 = both probes LDS-staged, 6 pair-batched chain,
+                                // 10 = 9 + pair-batched chain (default; falls back to 9 for an odd chain length); streamed ping-pong
+                                // kernels 3, 4 (LDS probes), 5 (all loads LDS-staged, counted vmcnt)
     bool timing_open = false;
 };
 
