@@ -14,6 +14,7 @@
 #include "host_secp.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 // keys[j*T + tid] = low 64 bits of x((first + j*T + tid) * G); only indices < count are written
@@ -168,6 +169,113 @@ static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img,
     HIPCHK(hipGetLastError());
     if (gpu_img && cpu_img) HIPCHK(hipMemcpyAsync(cpu_img, gpu_img, hdr, hipMemcpyDeviceToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
+    return BSGS_OK;
+}
+
+int bsgs_sort_u64(bsgs_dev *d, u64 *keys, uint64_t n)
+{
+    if (n < 2) return BSGS_OK;
+    DevBuf alt, tmp;
+    HIPCHK(alt.alloc(n * 8));
+    size_t tmp_bytes = 0;
+    rocprim::double_buffer<u64> db(keys, alt.as<u64>());
+    HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t)n, 0u, 64u, d->stream));
+    HIPCHK(tmp.alloc(tmp_bytes));
+    HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, db, (size_t)n, 0u, 64u, d->stream));
+    if (db.current() != keys) HIPCHK(hipMemcpyAsync(keys, db.current(), n * 8, hipMemcpyDeviceToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return BSGS_OK;
+}
+
+// expected number of entries beyond `cap` per bucket for Poisson(lambda) loads, times the number of buckets
+static double expected_overflow_entries(double lambda, unsigned cap, double buckets)
+{
+    // E[(X - cap)+] = sum_{c > cap} (c - cap) P(c); P by recurrence in log space
+    double e = 0.0;
+    const int top = (int)(lambda + 40.0 * std::sqrt(lambda + 1.0) + cap + 64);
+    double logp = -lambda;                                      // log P(0)
+    for (int c = 1; c <= top; c++) {
+        logp += std::log(lambda) - std::log((double)c);
+        if ((unsigned)c > cap) e += (double)(c - (int)cap) * std::exp(logp);
+    }
+    return e * buckets;
+}
+
+extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (!w || w > (1ull << 36) || htsz < 1 || htsz > 32) return fail(BSGS_ERR_ARG, "need 0 < w <= 2^36 and 1 <= htsz <= 32");
+    if (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "layout must be BSGS_TABLE_LINES64_LIST or BSGS_TABLE_LINES128_LIST");
+    HIPCHK(hipSetDevice(d->id));
+    bsgs_free_table(d);
+    const int lplog = layout == BSGS_TABLE_LINES128_LIST ? 3 : 2;
+    const unsigned cap_line = (4u << lplog) - 1;
+    const uint64_t ht_items = 1ull << htsz, line_bytes = 64ull << (lplog - 2);
+    // one generation chunk = T threads x pi points; large chunks keep the host-side base points (T per chunk) off the clock
+    const uint32_t T = 1u << 16, pi = w > (1ull << 28) ? 4096 : 512;
+    const uint64_t chunk = (uint64_t)T * pi;
+    const uint64_t ovf_cap = std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / (double)ht_items, cap_line, (double)ht_items)) + (1u << 20));
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    const uint64_t need = ht_items * line_bytes + ovf_cap * 16 + std::min(chunk, w) * 8 + (uint64_t)T * pi * 32 + (64ull << 20);
+    if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table needs %.1f GiB, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
+    u32x4 *lines = nullptr;
+    u64 *ovf = nullptr;
+    DevBuf keys, chainb, helperb, basesb, cnt;
+    HIPCHK(hipMalloc(&lines, ht_items * line_bytes));
+    hipError_t e = hipMalloc(&ovf, ovf_cap * 8);
+    if (e != hipSuccess) { (void)hipFree(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
+    struct Guard { u32x4 *&l; u64 *&o; ~Guard() { if (l) (void)hipFree(l); if (o) (void)hipFree(o); } } guard{lines, ovf};
+    HIPCHK(hipMemsetAsync(lines, 0, ht_items * line_bytes, d->stream));
+    HIPCHK(cnt.alloc(16));
+    HIPCHK(hipMemsetAsync(cnt.p, 0, 16, d->stream));
+    HIPCHK(keys.alloc(std::min(chunk, w) * 8));
+    HIPCHK(chainb.alloc((uint64_t)T * pi * 32));
+    const hs::Affine TG = hs::point_mul(hs::G, hs::fe_from_u64(T));
+    {
+        std::vector<hs::Affine> helper = hs::multiples(TG, pi - 1);
+        std::vector<uint8_t> hb((size_t)(pi - 1) * 64);
+        for (size_t i = 0; i + 1 < pi; i++) hs::affine_to_le(helper[i], &hb[i * 64], &hb[i * 64 + 32]);
+        HIPCHK(helperb.alloc(hb.size()));
+        HIPCHK(hipMemcpy(helperb.p, hb.data(), hb.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(basesb.alloc((size_t)T * 64));
+    std::vector<uint8_t> bb((size_t)T * 64);
+    const u32 mask = (u32)(ht_items - 1);
+    for (uint64_t first = 1; first <= w; first += chunk) {
+        const uint64_t count = std::min<uint64_t>(chunk, w - first + 1);
+        {
+            const hs::Affine start = hs::point_mul(hs::G, hs::fe_from_u64(first));
+            std::vector<hs::Jac> j(T);
+            hs::Jac cur = hs::to_jac(start);
+            for (uint32_t i = 0; i < T; i++) { j[i] = cur; cur = hs::jac_add_affine(cur, hs::G); }
+            std::vector<hs::Affine> a = hs::batch_to_affine(j);
+            HIPCHK(hipStreamSynchronize(d->stream));                 // bb is still the source of the previous chunk's copy
+            for (uint32_t i = 0; i < T; i++) hs::affine_to_le(a[i], &bb[(size_t)i * 64], &bb[(size_t)i * 64 + 32]);
+        }
+        HIPCHK(hipMemcpyAsync(basesb.p, bb.data(), bb.size(), hipMemcpyHostToDevice, d->stream));
+        hipLaunchKernelGGL(baby_keys_kernel, dim3(T / 256), dim3(256), 0, d->stream, helperb.as<const u32x4>(), basesb.as<const u32x4>(),
+                           keys.as<u64>(), chainb.as<u32x4>(), T, pi, count);
+        const int sblocks = (int)std::min<uint64_t>((count + 255) / 256, 1u << 16);
+        if (lplog == 2) hipLaunchKernelGGL(ext_scatter_kernel<2>, dim3(sblocks), dim3(256), 0, d->stream, keys.as<const u64>(), count, mask, (u32 *)lines, ovf, ovf_cap, cnt.as<unsigned long long>());
+        else            hipLaunchKernelGGL(ext_scatter_kernel<3>, dim3(sblocks), dim3(256), 0, d->stream, keys.as<const u64>(), count, mask, (u32 *)lines, ovf, ovf_cap, cnt.as<unsigned long long>());
+        HIPCHK(hipGetLastError());
+    }
+    const int fblocks = (int)std::min<uint64_t>((ht_items + 255) / 256, 1u << 20);
+    if (lplog == 2) hipLaunchKernelGGL(ext_finalize_kernel<2>, dim3(fblocks), dim3(256), 0, d->stream, (u32 *)lines, ht_items, cnt.as<unsigned long long>());
+    else            hipLaunchKernelGGL(ext_finalize_kernel<3>, dim3(fblocks), dim3(256), 0, d->stream, (u32 *)lines, ht_items, cnt.as<unsigned long long>());
+    HIPCHK(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (h[1] > ovf_cap) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries, capacity %llu", h[1], (unsigned long long)ovf_cap);
+    (void)hipFree(chainb.p); chainb.p = nullptr;
+    (void)hipFree(keys.p); keys.p = nullptr;
+    int rc = bsgs_sort_u64(d, ovf, h[1]);
+    if (rc) return rc;
+    rc = bsgs_install_lines(d, lines, lplog, ovf, h[1], ht_items, w, h[0]);
+    if (rc) return rc;
+    lines = nullptr; ovf = nullptr;                                   // owned by the engine now
     return BSGS_OK;
 }
 

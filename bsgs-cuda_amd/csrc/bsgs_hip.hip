@@ -69,8 +69,10 @@ static void free_table(bsgs_dev *d)
 {
     if (d->csr && d->csr_owned) (void)hipFree(d->csr);
     if (d->lines) (void)hipFree(d->lines);
-    d->csr = nullptr; d->lines = nullptr; d->layout = 0;
+    if (d->ovf) (void)hipFree(d->ovf);
+    d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0;
 }
+void bsgs_free_table(bsgs_dev *d) { free_table(d); }
 static void free_g2(bsgs_dev *d)
 {
     if (d->g2) (void)hipFree(d->g2);
@@ -257,24 +259,48 @@ extern "C" int bsgs_generate_g2(bsgs_dev *d, const uint8_t a_xy_le[64], uint32_t
 }
 
 // ---- baby table -----------------------------------------------------------------------------------------
-static int build_lines(bsgs_dev *d, uint32_t layout)
+// with_list: the entries that do not fit go to a sorted overflow list and the CSR image is dropped afterwards
+static int build_lines(bsgs_dev *d, uint32_t layout, bool with_list)
 {
     const int lplog = layout == BSGS_TABLE_LINES128 ? 3 : 2;
     d->lines_bytes = d->ht_items * (64ull << (lplog - 2));
     HIPCHK(hipMalloc(&d->lines, d->lines_bytes));
-    unsigned long long *ovf = nullptr;
-    HIPCHK(hipMalloc(&ovf, 8));
-    HIPCHK(hipMemsetAsync(ovf, 0, 8, d->stream));
+    unsigned long long *cnt = nullptr, h[2] = {0, 0};
+    HIPCHK(hipMalloc(&cnt, 16));
     const int blocks = (int)std::min<uint64_t>((d->ht_items + 255) / 256, 1u << 20);
-    if (lplog == 2) hipLaunchKernelGGL(lines_build_kernel<2>, dim3(blocks), dim3(256), 0, d->stream, d->csr, (u32 *)d->lines, d->ht_items, ovf);
-    else            hipLaunchKernelGGL(lines_build_kernel<3>, dim3(blocks), dim3(256), 0, d->stream, d->csr, (u32 *)d->lines, d->ht_items, ovf);
-    HIPCHK(hipGetLastError());
-    unsigned long long h = 0;
-    HIPCHK(hipMemcpyAsync(&h, ovf, 8, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    (void)hipFree(ovf);
-    d->overflow = h;
+    uint64_t cap = 0;
+    u64 *list = nullptr;
+    for (int pass = 0; pass < (with_list ? 2 : 1); pass++) {          // pass 0 of 2 only counts the overflow entries
+        HIPCHK(hipMemsetAsync(cnt, 0, 16, d->stream));
+        u64 *arg = with_list ? (pass ? list : (u64 *)cnt) : nullptr;   // any non-NULL pointer with capacity 0 in the counting pass
+        if (lplog == 2) hipLaunchKernelGGL(lines_build_kernel<2>, dim3(blocks), dim3(256), 0, d->stream, d->csr, (u32 *)d->lines, d->ht_items, cnt, arg, cap);
+        else            hipLaunchKernelGGL(lines_build_kernel<3>, dim3(blocks), dim3(256), 0, d->stream, d->csr, (u32 *)d->lines, d->ht_items, cnt, arg, cap);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h, cnt, 16, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (with_list && pass == 0) { cap = h[1]; HIPCHK(hipMalloc(&list, cap ? cap * 8 : 8)); }
+    }
+    (void)hipFree(cnt);
+    d->overflow = h[0];
     d->layout = layout;
+    if (with_list) {
+        int rc = bsgs_sort_u64(d, list, cap);
+        if (rc) { (void)hipFree(list); return rc; }
+        d->ovf = list; d->ovf_n = cap;
+        if (d->csr && d->csr_owned) (void)hipFree(d->csr);
+        d->csr = nullptr;                                               // borrowed images stay with the caller
+    }
+    return BSGS_OK;
+}
+
+int bsgs_install_lines(bsgs_dev *d, u32x4 *lines, int lplog, u64 *ovf, uint64_t ovf_n, uint64_t ht_items, uint64_t w,
+                       uint64_t overflow_buckets)
+{
+    free_table(d);
+    d->lines = lines; d->lines_bytes = ht_items * (64ull << (lplog - 2));
+    d->ovf = ovf; d->ovf_n = ovf_n;
+    d->ht_items = ht_items; d->w = w; d->overflow = overflow_buckets;
+    d->layout = lplog == 3 ? BSGS_TABLE_LINES128 : BSGS_TABLE_LINES64;
     return BSGS_OK;
 }
 
@@ -291,8 +317,10 @@ static int finish_table(bsgs_dev *d, uint64_t ht_items, uint64_t w, uint32_t lay
         if (load > 14.0 || need + (1ull << 30) > fr) layout = BSGS_TABLE_CSR;
     }
     if (layout == BSGS_TABLE_CSR) { d->layout = BSGS_TABLE_CSR; d->lines_bytes = 0; d->overflow = 0; return BSGS_OK; }
+    if (layout == BSGS_TABLE_LINES64_LIST) return build_lines(d, BSGS_TABLE_LINES64, true);
+    if (layout == BSGS_TABLE_LINES128_LIST) return build_lines(d, BSGS_TABLE_LINES128, true);
     if (layout != BSGS_TABLE_LINES64 && layout != BSGS_TABLE_LINES128) return fail(BSGS_ERR_ARG, "unknown layout %u", layout);
-    return build_lines(d, layout);
+    return build_lines(d, layout, false);
 }
 
 static int check_table_args(uint64_t ht_items, uint64_t w)
@@ -332,8 +360,8 @@ extern "C" int bsgs_table_info(bsgs_dev *d, uint32_t *layout, uint64_t *device_b
 {
     if (!d) return fail(BSGS_ERR_ARG, "null");
     if (!d->layout) return fail(BSGS_ERR_STATE, "no table on device");
-    if (layout) *layout = d->layout;
-    if (device_bytes) *device_bytes = 4 * (d->ht_items + 1) + 4 * d->w + d->lines_bytes;
+    if (layout) *layout = d->ovf ? d->layout + 2 : d->layout;        // 4 / 5: bucket lines + overflow list, no CSR image
+    if (device_bytes) *device_bytes = d->ovf ? d->lines_bytes + 8 * d->ovf_n : 4 * (d->ht_items + 1) + 4 * d->w + d->lines_bytes;
     if (overflow_buckets) *overflow_buckets = d->overflow;
     return BSGS_OK;
 }
@@ -345,7 +373,7 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
 {
     TileArgs A;
     hipStream_t st = which ? d->stream2 : d->stream;
-    A.g2 = d->g2; A.chain = d->chain + (which ? d->maxnonce * 2 * d->chain_tiles : 0); A.csr = d->csr; A.lines = d->lines; A.hitbuf = d->hitbuf;
+    A.g2 = d->g2; A.chain = d->chain + (which ? d->maxnonce * 2 * d->chain_tiles : 0); A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;
@@ -435,7 +463,7 @@ static int launch_stream(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, u
     d->pending_dev.push_back(dc);
     HIPCHK(hipMemcpyAsync(dc, pin, (size_t)ntiles * 64, hipMemcpyHostToDevice, d->stream));
     StreamArgs S;
-    S.g2 = d->g2; S.chain = d->schain; S.csr = d->csr; S.lines = d->lines; S.hitbuf = d->hitbuf; S.centres = (const fe *)dc;
+    S.g2 = d->g2; S.chain = d->schain; S.csr = d->csr; S.lines = d->lines; S.ovf = d->ovf; S.ovf_n = d->ovf_n; S.hitbuf = d->hitbuf; S.centres = (const fe *)dc;
     S.ht_items = d->ht_items; S.ht_mask = (u32)(d->ht_items - 1); S.pparam = d->pi; S.T = d->Ti; S.max_hits = d->max_hits;
     S.tile_seq = seq; S.ntiles = ntiles; S.ngroups = ng; S.debug_flags = d->debug_flags;
     const dim3 grid((unsigned)blocks), block(bs);

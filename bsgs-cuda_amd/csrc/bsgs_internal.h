@@ -37,8 +37,10 @@ struct bsgs_dev {
     u32 *csr = nullptr;         // htGPU image
     bool csr_owned = true;
     u32x4 *lines = nullptr;
+    u64 *ovf = nullptr;         // "lines + overflow list" formats (no CSR on the device): sorted (bucket << 32 | hash)
+    uint64_t ovf_n = 0;
     uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
-    uint32_t layout = 0;        // 1 csr, 2 lines64, 3 lines128
+    uint32_t layout = 0;        // probe layout: 1 csr, 2 lines64, 3 lines128 (ovf != NULL: reported as 4 / 5)
     u32 *hitbuf = nullptr;      // device
     u32 *hit_host = nullptr;    // pinned mirror
     uint32_t max_hits = 1u << 16;
@@ -51,4 +53,11 @@ struct bsgs_dev {
                                 // kernels 3, 4 (LDS probes), 5 (all loads LDS-staged, counted vmcnt)
     bool timing_open = false;
 };
+
+// shared between the translation units of the library
+void bsgs_free_table(bsgs_dev *d);
+int bsgs_sort_u64(bsgs_dev *d, u64 *keys, uint64_t n);      // in place, ascending (rocPRIM radix sort; baby_builder.hip)
+// hand a finished "lines + overflow list" table to the engine (it becomes the owner of both buffers)
+int bsgs_install_lines(bsgs_dev *d, u32x4 *lines, int lplog, u64 *ovf, uint64_t ovf_n, uint64_t ht_items, uint64_t w,
+                       uint64_t overflow_buckets);
 

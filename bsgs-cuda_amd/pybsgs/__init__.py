@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(HERE)
 LIB_PATH = os.environ.get("BSGS_LIB_PATH") or os.path.join(PKG_ROOT, "build", "libbsgs_hip.so")   # override: A/B of alternative builds
 
-TABLE_AUTO, TABLE_CSR, TABLE_LINES64, TABLE_LINES128 = 0, 1, 2, 3
+TABLE_AUTO, TABLE_CSR, TABLE_LINES64, TABLE_LINES128, TABLE_LINES64_LIST, TABLE_LINES128_LIST = 0, 1, 2, 3, 4, 5
 ERR_OVERFLOW = -5
 
 # every symbol include/bsgs_hip.h declares (checked by tests/test_abi.py)
@@ -20,7 +20,7 @@ NATIVE_SYMBOLS = [
     "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
-    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_profile_phases",
+    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_profile_phases",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -83,6 +83,7 @@ def lib():
             "bsgs_launch_count": [vp, C.POINTER(C.c_uint64)],
             "bsgs_build_baby_tables": [vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32],
             "bsgs_build_baby_tables_device": [vp, C.c_uint64, C.c_uint32, vp, vp],
+            "bsgs_build_baby_table_ext": [vp, C.c_uint64, C.c_uint32, C.c_uint32],
             "bsgs_profile_phases": [vp, u8p, C.c_uint32, C.POINTER(C.c_float)],
         }
         for name, args in sig.items():
@@ -171,6 +172,10 @@ class Device:
     def build_baby_tables_device(self, w, htsz, htgpu_dptr, htcpu_dptr=None):
         _chk(self.L.bsgs_build_baby_tables_device(self.h, w, htsz, C.c_void_p(htgpu_dptr) if htgpu_dptr else None,
                                                   C.c_void_p(htcpu_dptr) if htcpu_dptr else None))
+
+    def build_baby_table_ext(self, w, htsz, layout=TABLE_LINES64_LIST):
+        """k*G, k = 1..w (w up to 2^36) straight into bucket lines + overflow list on the device (no CSR, no positions)"""
+        _chk(self.L.bsgs_build_baby_table_ext(self.h, w, htsz, layout))
 
     def table_info(self):
         lay, nb, ov = C.c_uint32(), C.c_uint64(), C.c_uint64()

@@ -45,13 +45,23 @@ def test_fullsize_planted_and_layout_agreement(wexp, htsz):
           3 * 2 * w * 1000003 + (w - 7)]
     centres = [ecpy.mul(m % N) for m in ms]
     results = {}
-    for layout in (pybsgs.TABLE_LINES64, pybsgs.TABLE_CSR):
+    for layout in (pybsgs.TABLE_LINES64, pybsgs.TABLE_CSR, pybsgs.TABLE_LINES64_LIST):
         dev.upload_htgpu_device(img.data_ptr(), 1 << htsz, w, layout)
         assert dev.table_info()[0] == layout
         hits, n, _ = dev.run(centres, 65536)
         assert n == len(hits)
         results[layout] = hits
     assert results[pybsgs.TABLE_LINES64] == results[pybsgs.TABLE_CSR]          # two probe implementations, one answer
+    assert results[pybsgs.TABLE_LINES64_LIST] == results[pybsgs.TABLE_CSR]     # lines + overflow list, CSR dropped
+    if wexp == 30:
+        # the direct builder (atomic scatter, no sort, no CSR: the w >= 2^32 path) must give the same table semantics
+        del img
+        torch.cuda.empty_cache()
+        dev.build_baby_table_ext(w, htsz, pybsgs.TABLE_LINES64_LIST)
+        lay, nbytes, ovf = dev.table_info()
+        assert lay == pybsgs.TABLE_LINES64_LIST and nbytes >= 64 << htsz and ovf > 0
+        hits, n, _ = dev.run(centres, 65536)
+        assert hits == results[pybsgs.TABLE_CSR]
     got = results[pybsgs.TABLE_LINES64]
     extra = 0
     for k, m in enumerate(ms):
@@ -62,4 +72,46 @@ def test_fullsize_planted_and_layout_agreement(wexp, htsz):
     # 32-bit hash collisions: ~ 2 * maxnonce * (w / 2^htsz) / 2^32 per tile  (0.016 at -w 26, 0.03 at -w 30)
     assert extra <= 3
     assert ms[5] and not analytic_hits(ms[5], w, maxnonce)
+    dev.close()
+
+
+def test_extended_table_w34():
+    """BASELINE configs 3/5 geometry: -w 34 -htsz 31 (2^34 baby points, 128 GiB of bucket lines + overflow list), built on
+    the GPU by bsgs_build_baby_table_ext.  No reference format exists at this size (1_9_7File.pb:4412-4418 caps w below
+    2^32), so parity is through the analytic hit list of crafted centres; everything else must be a hash collision
+    (expected 2 * 2^24 * 8 / 2^32 = 0.06 per tile)."""
+    import pybsgs
+    from pybsgs import ecpy
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 200 * 2**30:
+        pytest.skip("needs ~150 GiB of free HBM")
+    wexp, htsz = 34, 31
+    t, b, p, w = 256, 256, 256, 1 << wexp
+    maxnonce = t * b * p
+    dev = pybsgs.Device(0)
+    dev.build_baby_table_ext(w, htsz, pybsgs.TABLE_LINES64_LIST)
+    lay, nbytes, ovf = dev.table_info()
+    assert lay == pybsgs.TABLE_LINES64_LIST and nbytes >= 64 << htsz
+    assert 0.005 * 2**31 < ovf < 0.012 * 2**31          # P(Poisson(8) > 15) = 0.82 % of the buckets overflow a 64-byte line
+    A = ecpy.addpubg(w)
+    dev.generate_g2(A[0], A[1], t, b, p)
+    ms = [(0 + 1) * 2 * w + 77,                       # code 1 at the first giant, b' = 77
+          -((maxnonce) * 2 * w) + 12345,              # code 2 at the last giant
+          (maxnonce // 2) * 2 * w - w,                # edge b' = w (the LAST baby point, k = 2^34): two adjacent giants
+          w // 3,                                     # code 5
+          -(5000001 * 2 * w) - 1,                     # code 2, b' = 1
+          (maxnonce + 5) * 2 * w + 99,                # beyond the last giant: nothing
+          3 * 2 * w * 1000003 + (w - 7),
+          7 * 2 * w + (1 << 32) + 5,                  # baby indices around the 32-bit boundary of the reference format
+          9 * 2 * w + (1 << 33) - 1]
+    centres = [ecpy.mul(m % N) for m in ms]
+    got, n, _ = dev.run(centres, 65536)
+    assert n == len(got)
+    extra = 0
+    for k, m in enumerate(ms):
+        mine = [(c, i) for tile, c, i in got if tile == k]
+        expect = analytic_hits(m, w, maxnonce)
+        assert set(expect) <= set(mine), (k, expect, mine)
+        extra += len(mine) - len(expect)
+    assert extra <= 4
     dev.close()

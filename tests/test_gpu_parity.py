@@ -122,8 +122,40 @@ def test_gpu_baby_table_builder(dev, O, small_fx):
         assert ((5, 0xFFFFFFFF) in hits) == expect, k
 
 
+def test_direct_line_builder_matches_oracle_tables(dev, O, small_fx):
+    """bsgs_build_baby_table_ext (scatter into bucket lines + overflow list, the w >= 2^32 path) at small sizes: the
+    fixture's hit lists, and the oracle's tiles over the oracle's own table for loads of 4, 64 and 680 per bucket."""
+    fx = small_fx
+    dev.upload_g2(bytes.fromhex(fx["g2"]), fx["t"], fx["b"], fx["p"])
+    for layout in (4, 5):
+        dev.build_baby_table_ext(fx["w"], fx["htsz"], layout)
+        assert dev.table_info()[0] == layout
+        for tl in fx["tiles"] + fx["known_key"]["walk"]:
+            hits, n = dev.step(int(tl["px"], 16), int(tl["py"], 16))
+            assert [list(h) for h in hits] == tl["hits"], (layout, tl.get("kind", "walk"))
+    t, b, p = 64, 3, 20
+    rnd = random.Random(31)
+    for w, htsz in ((1 << 14, 12), (1 << 14, 8), (70001, 7)):
+        g2 = O.build_g2(t, b, p, w)
+        gpu, _ = O.build_baby_tables(w, htsz)
+        dev.upload_g2(g2, t, b, p)
+        n = t * b * p
+        # centres that do hit: m*G with m = +-(i+1)*2w + b' (SURVEY.md Appendix B) and the table's own points
+        ms = [rnd.randrange(1, n) * 2 * w + rnd.randrange(1, w) for _ in range(3)] + [-(rnd.randrange(1, n) * 2 * w) - 5, w, 1]
+        N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+        centres = [O.pt_mul(m % N) for m in ms]
+        for layout in (4, 5):
+            dev.build_baby_table_ext(w, htsz, layout)
+            lay, _, ovf = dev.table_info()
+            assert lay == layout and (ovf > 0) == (w / (1 << htsz) > 40)
+            for Pt in centres:
+                ref, nref = O.tile_ref(Pt, g2, t, b, p, gpu, htsz, 0, 65536)
+                hits, nh = dev.step(Pt[0], Pt[1], 65536)
+                assert (nh, hits) == (nref, ref) and nref > 0, (w, htsz, layout)
+
+
 # ------------------------------------------------------------------------------------------ tiles
-LAYOUTS = [1, 2, 3]      # CSR, 64-byte lines, 128-byte lines
+LAYOUTS = [1, 2, 3, 4, 5]      # CSR, 64-byte lines, 128-byte lines, the same two with an overflow list instead of the CSR
 
 
 @pytest.mark.parametrize("layout", LAYOUTS)
@@ -167,7 +199,7 @@ def test_planted_tiles_match_oracle(dev, O, layout, htsz):
     dev.upload_htgpu(gpu, 1 << htsz, w, layout)
     lay, _, ovf = dev.table_info()
     assert lay == layout
-    if layout == 2 and htsz == 10:
+    if layout in (2, 4) and htsz == 10:
         assert ovf > 1000                                # nearly every bucket overflows a 64-byte line
     total = 0
     for k, Pt in enumerate(centres):
@@ -196,7 +228,7 @@ def test_false_positives_match_oracle(dev, O):
     gpu, _ = O.pack_tables_from_keys(keys, htsz)
     dev.upload_g2(g2, t, b, p)
     seen = 0
-    for layout in (1, 2):
+    for layout in (1, 2, 4):
         dev.upload_htgpu(gpu, 1 << htsz, w, layout)
         for s in range(3):
             Pt = O.pt_mul(rnd.randrange(1, 2**200))
