@@ -78,7 +78,7 @@ static void free_g2(bsgs_dev *d)
     if (d->g2) (void)hipFree(d->g2);
     if (d->chain) (void)hipFree(d->chain);
     if (d->schain) (void)hipFree(d->schain);
-    d->g2 = nullptr; d->chain = nullptr; d->schain = nullptr; d->schain_blocks = 0;
+    d->g2 = nullptr; d->chain = nullptr; d->chain_bytes = 0; d->schain = nullptr; d->schain_blocks = 0;
 }
 
 extern "C" int bsgs_dev_close(bsgs_dev *d)
@@ -162,18 +162,28 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     else while ((uint64_t)p * m * 2 <= 1024 && T % (2ull * m) == 0 && T / (2ull * m) >= 2048 && (T / (2ull * m)) % 256 == 0) m *= 2;
     if (T % m) m = 1;
     d->Ti = (uint32_t)(T / m); d->pi = p * m;
-    d->chain_tiles = 0;
     HIPCHK(hipMalloc(&d->g2, maxnonce * 64));
     return BSGS_OK;
 }
 
-// the prefix-product scratch: 32 bytes per giant per tile in flight
-static int ensure_chain(bsgs_dev *d, uint64_t tiles)
+// the prefix-product scratch: 32 bytes per giant per tile in flight (16 for the pair-batched default kernel, which stores
+// one product per two giants); `full` = the caller is a generator kernel that needs the per-giant chain of one tile
+static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
 {
-    if (d->chain && d->chain_tiles >= tiles) return BSGS_OK;
-    if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; }
-    HIPCHK(hipMalloc(&d->chain, d->maxnonce * 32 * tiles * 2));          // one scratch per stream
-    d->chain_tiles = tiles;
+    const bool halfchain = !full && d->variant == 10 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);   // = the dispatch of giant_pair2_kernel
+    const uint64_t per_stream = d->maxnonce * (halfchain ? 16 : 32) * tiles;
+    const uint64_t bytes = per_stream * (d->nstreams == 2 ? 2 : 1);                 // one scratch per stream
+    if (d->chain && d->chain_bytes >= bytes) { d->chain_stride = per_stream / 16; return BSGS_OK; }
+    if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
+    if (hipMalloc(&d->chain, bytes) != hipSuccess) {
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        d->chain = nullptr;
+        return fail(BSGS_ERR_NOMEM, "chain scratch: %.1f GiB for %llu tiles in flight, %.1f of %.1f GiB free", bytes / 1073741824.0,
+                    (unsigned long long)tiles, fr / 1073741824.0, tot / 1073741824.0);
+    }
+    d->chain_bytes = bytes;
+    d->chain_stride = per_stream / 16;
     return BSGS_OK;
 }
 static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
@@ -247,7 +257,7 @@ extern "C" int bsgs_generate_g2(bsgs_dev *d, const uint8_t a_xy_le[64], uint32_t
     HIPCHK(hipMemcpy(dh, hbuf.data(), hbuf.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(db, bbuf.data(), bbuf.size(), hipMemcpyHostToDevice));
     const int blocks = (int)((Ti + 255) / 256);
-    int rcc = ensure_chain(d, 1);
+    int rcc = ensure_chain(d, 1, true);
     if (rcc) { (void)hipFree(dh); (void)hipFree(db); return rcc; }
     hipLaunchKernelGGL(g2_generate_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)dh, (const u32x4 *)db,
                        d->g2, d->chain, Ti, pi);
@@ -373,7 +383,7 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
 {
     TileArgs A;
     hipStream_t st = which ? d->stream2 : d->stream;
-    A.g2 = d->g2; A.chain = d->chain + (which ? d->maxnonce * 2 * d->chain_tiles : 0); A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
+    A.g2 = d->g2; A.chain = d->chain + (which ? d->chain_stride : 0); A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;

@@ -27,7 +27,7 @@ struct bsgs_dev {
     uint32_t t = 0, b = 0, p = 0;          // the caller's geometry (file layout, hit index i = tid*p + j)
     uint64_t T = 0, maxnonce = 0;
     uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
-    uint64_t chain_tiles = 0;              // tiles the chain scratch is currently sized for
+    uint64_t chain_bytes = 0, chain_stride = 0;   // size of the chain scratch; u32x4 elements per stream
     u32x4 *schain = nullptr;               // streamed kernel: one scratch slot per resident block
     uint64_t schain_blocks = 0;
     std::vector<void *> pending_dev, pending_pinned;   // per-enqueue centre buffers, released by bsgs_collect

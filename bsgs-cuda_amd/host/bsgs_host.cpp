@@ -26,6 +26,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <algorithm>
 
 using hs::Affine;
 using hs::Scalar;
@@ -76,6 +77,7 @@ struct Config {
     int wt = 180;
     bool onlygen = false;                          // onlygen_1_9_6File0.exe behaviour: build files and exit
     uint64_t max_tiles = 0;                        // test hook: stop after this many tiles (0 = unlimited)
+    bool ext = false;                              // extended table (bucket lines + overflow list, no HT files); implied by w >= 3069485951
     std::string dir = ".";                         // where table / output files live
 };
 
@@ -98,7 +100,8 @@ static void usage(const Config &c)
            "-pk      Range start from , default %s\n-pke     End range \n-w       Set number of baby items 2^ or decimal representation\n"
            "-htsz    Set number of HashTable 2^ , default %u\n-infile  Set file with pubkey for searching in uncompressed/compressed  format (search sequential)\n"
            "-wl      Set recovery file from which the state will be loaded\n-wt      Set timer for autosaving current state, default every %dseconds\n"
-           "-onlygen Generate the table files and exit (onlygen_1_9_6File0.exe)\n-dir     Directory for table files, currentwork.txt and win.txt\n",
+           "-onlygen Generate the table files and exit (onlygen_1_9_6File0.exe)\n-dir     Directory for table files, currentwork.txt and win.txt\n"
+           "-ext     Extended baby table built in GPU memory (no HT files); automatic for -w above the reference limit, up to 2^36\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
 }
 
@@ -120,7 +123,8 @@ static Config parse_args(int argc, char **argv)
         else if (a == "-w") {                                   // <=32: 2^value (fractional allowed), else decimal  (1009-1022)
             const std::string v = next();
             const double d = atof(v.c_str());
-            if (d <= 32.0) { c.w = (uint64_t)std::pow(2.0, d); printf("Items number set to 2^%s=%llu\n", v.c_str(), (unsigned long long)c.w); }
+            // the reference switches to decimal above 32; 33..36 are exponents of the extended table here
+            if (d <= 36.0) { c.w = (uint64_t)std::pow(2.0, d); printf("Items number set to 2^%s=%llu\n", v.c_str(), (unsigned long long)c.w); }
             else { c.w = strtoull(v.c_str(), nullptr, 10); printf("Items number set to %llu = 2^%f\n", (unsigned long long)c.w, std::log2((double)c.w)); }
         }
         else if (a == "-htsz") { c.htsz = (uint32_t)atoi(next().c_str()); printf("HT size set to 2^%u\n", c.htsz); }
@@ -130,10 +134,15 @@ static Config parse_args(int argc, char **argv)
         else if (a == "-onlygen") c.onlygen = true;
         else if (a == "-maxtiles") c.max_tiles = strtoull(next().c_str(), nullptr, 10);
         else if (a == "-dir") c.dir = next();
+        else if (a == "-ext") c.ext = true;
         else die("Unknown parameter " + a);
     }
     // limits 1_9_7File.pb:4412-4418, 4616-4618
-    if (c.w >= 3069485951ull) die("-w must be less than 3069485951");
+    if (c.w >= 3069485951ull) {                    // beyond the reference's u32 file format: extended device-resident table
+        if (c.w > (1ull << 36)) die("-w must be at most 2^36");
+        c.ext = true;
+        printf("-w above the reference limit 3069485951: extended table in GPU memory, no HT files\n");
+    }
     if (c.htsz > 31 || c.htsz < 1) die("-htsz must be 1..31");
     if (c.p & 1) die("-p must be even");
     if (!c.t || !c.b || !c.p) die("-t -b -p must be non-zero");
@@ -162,6 +171,15 @@ static void write_file(const std::string &path, const void *p, uint64_t n)
 #define CK(call) do { int rc_ = (call); if (rc_ != BSGS_OK) die(std::string("error " #call "-") + std::to_string(rc_) + ": " + bsgs_last_error()); } while (0)
 
 // ---- shared state (the reference's globals *GlobKey / GlobPub / checker() / quit) ------------------------------
+struct MiniBsgs {
+    unsigned mb = 0;
+    std::vector<std::pair<uint64_t, uint32_t>> baby;     // (low 64 bits of x(jG), j), j = 1..2^mb, sorted
+    Affine Q;                                            // 2^mb * G
+    void build(uint64_t w, unsigned threads);
+    size_t lookup(uint64_t x64) const;
+    std::vector<uint64_t> find(const Affine &T, uint64_t w) const;     // every b' in [1, w] with x(b'G) = x(T)
+};
+
 struct Tile { Scalar key; Affine pub; };
 struct PendingHit { uint32_t code, idx; Tile tile; };
 
@@ -187,6 +205,7 @@ struct Shared {
     Scalar winkey;
     bool found = false;
     std::vector<uint8_t> htcpu;
+    MiniBsgs mini;                                // extended tables: the resolver's own small BSGS instead of htCPU
     int listpos = 1;
     std::string mainpub_hex;
 };
@@ -232,6 +251,75 @@ static int htcpu_lookup(const std::vector<uint8_t> &img, uint64_t ht_items, uint
     return n;
 }
 
+// Extended tables have no htCPU (positions): the baby index b' of a hit, x(b'G) = x(T), 1 <= b' <= w, is found by a small
+// BSGS of its own: 2^mb stored multiples of G, then T -+ i*(2^mb G) for i <= w / 2^mb, normalised in batches.
+size_t MiniBsgs::lookup(uint64_t x64) const
+{
+    auto it = std::lower_bound(baby.begin(), baby.end(), std::make_pair(x64, (uint32_t)0));
+    return (it != baby.end() && it->first == x64) ? (size_t)(it - baby.begin()) : (size_t)-1;
+}
+void MiniBsgs::build(uint64_t w, unsigned threads)
+{
+    unsigned lw = 0; while ((1ull << lw) < w) lw++;
+    mb = std::min(22u, std::max(8u, lw / 2 + 5));
+    const uint64_t M = 1ull << mb;
+    baby.resize(M);
+    Q = hs::point_mul(hs::G, hs::fe_from_u64(M));
+    threads = std::max(1u, std::min(threads, 64u));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++) th.emplace_back([&, t]() {
+        const uint64_t lo = 1 + M * t / threads, hi = 1 + M * (t + 1) / threads;          // j in [lo, hi)
+        hs::Jac cur = hs::to_jac(hs::point_mul(hs::G, hs::fe_from_u64(lo)));
+        std::vector<hs::Jac> blk;
+        for (uint64_t j = lo; j < hi;) {
+            blk.clear();
+            const uint64_t n = std::min<uint64_t>(4096, hi - j);
+            for (uint64_t k = 0; k < n; k++) { blk.push_back(cur); cur = hs::jac_add_affine(cur, hs::G); }
+            const std::vector<Affine> a = hs::batch_to_affine(blk);
+            for (uint64_t k = 0; k < n; k++) baby[j - 1 + k] = {a[k].x.l[0], (uint32_t)(j + k)};
+            j += n;
+        }
+    });
+    for (auto &x : th) x.join();
+    std::sort(baby.begin(), baby.end());
+}
+std::vector<uint64_t> MiniBsgs::find(const Affine &T, uint64_t w) const
+{
+    std::vector<uint64_t> cand, out;
+    const uint64_t M = 1ull << mb, I = w / M + 1;
+    const Affine nQ = hs::affine_neg(Q);
+    hs::Jac up = hs::to_jac(T), dn = hs::to_jac(T);
+    std::vector<hs::Jac> blk;
+    std::vector<uint64_t> idx;
+    for (uint64_t i = 0; i <= I;) {
+        blk.clear(); idx.clear();
+        for (int k = 0; k < 256 && i <= I; k++, i++) {
+            blk.push_back(up); idx.push_back(i);
+            if (i) { blk.push_back(dn); idx.push_back(i); }
+            up = hs::jac_add_affine(up, Q); dn = hs::jac_add_affine(dn, nQ);
+        }
+        const std::vector<Affine> a = hs::batch_to_affine(blk);
+        for (size_t k = 0; k < a.size(); k++) {
+            const uint64_t base = idx[k] * M;
+            if (a[k].inf) { cand.push_back(base); continue; }
+            const size_t at = lookup(a[k].x.l[0]);
+            if (at == (size_t)-1) continue;
+            for (size_t q = at; q < baby.size() && baby[q].first == a[k].x.l[0]; q++) {
+                cand.push_back(base + baby[q].second);
+                if (base >= baby[q].second) cand.push_back(base - baby[q].second);
+            }
+        }
+    }
+    std::sort(cand.begin(), cand.end());
+    cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+    for (uint64_t b : cand) {
+        if (b < 1 || b > w) continue;
+        const Affine v = hs::point_mul(hs::G, hs::fe_from_u64(b));
+        if (!v.inf && hs::fe_equal(v.x, T.x)) out.push_back(b);
+    }
+    return out;
+}
+
 static bool try_key(const Shared &S, const Scalar &kprime, Scalar &key_out)
 {
     const Affine tp = hs::point_mul(hs::G, kprime);
@@ -260,11 +348,15 @@ static bool resolve_hit(const Shared &S, const PendingHit &hit, Scalar &key_out)
         T = hs::point_add(hit.tile.pub, gi);
         if (T.inf) return false;
     }
-    uint32_t pos[64];
-    int np = htcpu_lookup(S.htcpu, 1ull << S.cfg.htsz, T.x.l[0], pos, 64);
-    if (np > 64) np = 64;
-    for (int q = 0; q < np; q++) {
-        const Scalar bb = hs::fe_from_u64((uint64_t)pos[q] + 1);
+    std::vector<uint64_t> babies;                 // b' with x(b'G) = x(T) as far as the table knows
+    if (S.cfg.ext) babies = S.mini.find(T, S.cfg.w);
+    else {
+        uint32_t pos[64];
+        int np = htcpu_lookup(S.htcpu, 1ull << S.cfg.htsz, T.x.l[0], pos, 64);
+        for (int q = 0; q < std::min(np, 64); q++) babies.push_back((uint64_t)pos[q] + 1);
+    }
+    for (uint64_t bprime : babies) {
+        const Scalar bb = hs::fe_from_u64(bprime);
         for (int s1 = 0; s1 < 2; s1++) {
             Scalar e1g;
             if (hit.code == 5) { if (s1) break; e1g = base; }
@@ -290,6 +382,7 @@ static void checker_thread(Shared *S)
         if (S->quit.load()) continue;
         Scalar key;
         if (resolve_hit(*S, hit, key)) {
+            std::lock_guard<std::mutex> lk(S->chk_mutex);
             S->winkey = key; S->found = true;
             S->quit.store(true);
         }
@@ -308,7 +401,16 @@ static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8
     CK(bsgs_dev_meminfo(dev, &fr, &tot));
     printf("GPU #%d %s memory %.0f/%.0f MB\n", gpu, name, fr / 1048576.0, tot / 1048576.0);
     CK(bsgs_upload_g2(dev, g2.data(), S.cfg.t, S.cfg.b, S.cfg.p));
-    CK(bsgs_upload_htgpu(dev, htgpu.data(), 1ull << S.cfg.htsz, S.cfg.w, BSGS_TABLE_AUTO));
+    if (S.cfg.ext) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const double load = (double)S.cfg.w / (double)(1ull << S.cfg.htsz);
+        const bool fits128 = (128ull << S.cfg.htsz) + (24ull << 30) < fr;
+        CK(bsgs_build_baby_table_ext(dev, S.cfg.w, S.cfg.htsz, load > 5.0 && fits128 ? BSGS_TABLE_LINES128_LIST : BSGS_TABLE_LINES64_LIST));
+        uint32_t lay = 0; uint64_t bytes = 0, ovf = 0;
+        CK(bsgs_table_info(dev, &lay, &bytes, &ovf));
+        printf("GPU #%d extended table: %llu items, %.1f GiB in memory, %llu over-full buckets, built in %.1fs\n", gpu, (unsigned long long)S.cfg.w,
+               bytes / 1073741824.0, (unsigned long long)ovf, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    } else CK(bsgs_upload_htgpu(dev, htgpu.data(), 1ull << S.cfg.htsz, S.cfg.w, BSGS_TABLE_AUTO));
     return dev;
 }
 
@@ -419,7 +521,8 @@ int main(int argc, char **argv)
     const uint64_t gpu_bytes = 4 * (ht_items + 1) + 4 * c.w, cpu_bytes = 4 * (ht_items + 1) + 8 * c.w, g2_bytes = 64 * S.maxnonce;
     bsgs_dev *d0 = nullptr;
     auto dev0 = [&]() { if (!d0) CK(bsgs_dev_open(gpus[0], &d0)); return d0; };
-    if (read_file(f_gpu, htgpu, gpu_bytes) && read_file(f_cpu, S.htcpu, cpu_bytes)) printf("Both HT files exist\n");
+    if (c.ext) printf("Extended table: %llu items, built in GPU memory at start-up (no HT files)\n", (unsigned long long)c.w);
+    else if (read_file(f_gpu, htgpu, gpu_bytes) && read_file(f_cpu, S.htcpu, cpu_bytes)) printf("Both HT files exist\n");
     else {
         printf("Generate HT with %llu items on the GPU\n", (unsigned long long)c.w);
         const auto t0 = std::chrono::steady_clock::now();
@@ -475,8 +578,17 @@ int main(int argc, char **argv)
         while (std::getline(f, line)) { while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back(); if (!line.empty()) pubs.push_back(cut_hex(line)); }
     } else pubs.push_back(c.pub);
 
-    std::vector<bsgs_dev *> devs;
-    for (int g : gpus) devs.push_back(open_and_load(S, g, htgpu, g2));
+    if (c.ext) {
+        const auto t0 = std::chrono::steady_clock::now();
+        S.mini.build(c.w, std::thread::hardware_concurrency());
+        printf("Resolver table: 2^%u multiples of G in %.1fs\n", S.mini.mb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    std::vector<bsgs_dev *> devs(gpus.size(), nullptr);
+    {   // one loader thread per GPU (each builds / uploads its own replica; 1_9_7File.pb:4769-4843 starts them the same way)
+        std::vector<std::thread> ld;
+        for (size_t gi = 0; gi < gpus.size(); gi++) ld.emplace_back([&, gi]() { devs[gi] = open_and_load(S, gpus[gi], htgpu, g2); });
+        for (auto &x : ld) x.join();
+    }
     std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
     std::vector<uint8_t>().swap(g2);
 
@@ -501,7 +613,9 @@ int main(int argc, char **argv)
         bool is_trivial = false;
         for (const Scalar &k : {one, two}) { const Affine q = hs::point_mul(hs::G, k); if (hs::fe_equal(q.x, S.realpub.x) && hs::fe_equal(q.y, S.realpub.y)) { trivial = k; is_trivial = true; } }
         if (!is_trivial) {
-            std::thread chk(checker_thread, &S);
+            const unsigned nchk = c.ext ? std::max(2u, std::min(16u, std::thread::hardware_concurrency() / 4)) : 1u;   // false positives cost a small BSGS each
+            std::vector<std::thread> chk;
+            for (unsigned q = 0; q < nchk; q++) chk.emplace_back(checker_thread, &S);
             std::vector<std::thread> th;
             S.inflight.assign(gpus.size(), hs::fe_from_u64(0)); S.inflight_valid.assign(gpus.size(), false);
             for (size_t gi = 0; gi < gpus.size(); gi++) th.emplace_back(gpu_thread, &S, gpus[gi], (int)gi, devs[gi]);
@@ -525,7 +639,7 @@ int main(int argc, char **argv)
             // drain the checker queue, then stop it
             for (;;) { { std::lock_guard<std::mutex> lk(S.chk_mutex); if (S.checker.empty()) break; } if (S.quit.load()) break; std::this_thread::sleep_for(std::chrono::milliseconds(10)); }
             S.all_done = true; S.chk_cv.notify_all();
-            chk.join();
+            for (auto &x : chk) x.join();
         } else { S.winkey = trivial; S.found = true; }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (S.found) {                                                  // win.txt 1_9_7File.pb:5146-5160

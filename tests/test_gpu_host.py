@@ -112,3 +112,30 @@ def test_config4_style_many_keys_64bit_range(tmp_path):
     got = [int(l.split("0x")[1], 16) for l in lines if l.startswith("KEY[")]
     assert got == keys
     assert out.count("memory") == 1                                      # one device, opened and loaded once
+
+
+def test_extended_table_mode_small_and_puzzle64(tmp_path):
+    """-ext: bucket lines + overflow list built in GPU memory, no HT files, hits resolved by the checker's own small BSGS
+    instead of an htCPU lookup -- same keys as the file-backed runs above"""
+    out = run(["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14", "-pb", PUB_1E9AD, "-pk", "1", "-ext"], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
+    assert "extended table" in out and not [f for f in os.listdir(tmp_path) if "htGPU" in f or "htCPU" in f]
+    run(["-t", "256", "-b", "64", "-p", "256", "-w", "26", "-htsz", "22", "-ext", "-pb", PUB_PUZZLE64,
+         "-pk", "8000000000000000", "-pke", "ffffffffffffffff"], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0xf7051f27b09112d4
+
+
+def test_config3_style_w34_80bit_range(tmp_path):
+    """BASELINE config 3 geometry: single key in an 80-bit range with -w 34 -htsz 31 (2^34 baby points, ~130 GiB of HBM,
+    beyond the reference's file format).  The key sits 2^65 into the range so the test stays short."""
+    import sys
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < 200 * 2**30:
+        pytest.skip("needs ~150 GiB of free HBM")
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    key = (1 << 79) + 0x2123456789ABCDEF0
+    out = run(["-t", "256", "-b", "256", "-p", "256", "-w", "34", "-htsz", "31", "-pb", "%064x%064x" % ecpy.mul(key),
+               "-pk", "80000000000000000000", "-pke", "ffffffffffffffffffff"], tmp_path, timeout=900)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % key
+    assert "17179869184 items" in out
