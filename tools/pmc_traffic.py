@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Reduce the per-pass summaries written by tools/profile_round.sh into profiles/<tag>_pmc_traffic.json
+(the file bench.py reads for roofline.traffic and the ALU-side figures).
+
+  tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/<tag>_pmc_traffic.json [steps_per_launch]
+"""
+import csv
+import json
+import os
+import sys
+
+
+def rows(path):
+    if not os.path.exists(path):
+        return []
+    return list(csv.DictReader(open(path)))
+
+
+def pick(d, counter, kernel_sub, exclude=None):
+    for name in sorted(os.listdir(d)):
+        if not name.startswith("rocprofv3_pmc_"):
+            continue
+        for r in rows(os.path.join(d, name)):
+            if r["counter"] == counter and kernel_sub in r["kernel"] and not (exclude and exclude in r["kernel"]):
+                return float(r["mean"]), int(r["dispatches"]), r["kernel"]
+    return None, 0, None
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 30
+    prod = ", false>"                                   # production instantiation (PHASE_PROBE = false)
+    fetch, nf, kname = pick(d, "FETCH_SIZE", "giant_", None)
+    fetch, nf, kname = pick(d, "FETCH_SIZE", prod)
+    write, _, _ = pick(d, "WRITE_SIZE", prod)
+    gups, _, _ = pick(d, "FETCH_SIZE", "mb_gups_kernel")
+    res = {
+        "source": "tools/profile_round.sh (rocprofv3 --pmc, one counter group per pass, never combined with traces) on `python bench.py "
+                  "--no-cpu-baseline`; per-kernel means in profiles/%s_rocprofv3_pmc_*.csv" % os.path.basename(out).split("_pmc_")[0],
+        "kernel": kname, "dispatches_averaged": nf, "steps_per_launch": steps,
+        "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB; bytes = value * 1024 (guide: HBM section)",
+        "fetch_bytes_per_launch": fetch * 1024, "write_bytes_per_launch": write * 1024,
+        "fetch_bytes_per_step": fetch * 1024 / steps, "write_bytes_per_step": write * 1024 / steps,
+        "algorithmic_bytes_per_step": 64,
+    }
+    if gups:
+        res["calibration"] = {"kernel": "mb_gups_kernel<4> (random 64-byte reads of the same run: 2^28 lines)", "fetch_bytes_measured": gups * 1024,
+                              "bytes_expected": float(1 << 34), "ratio": gups * 1024 / float(1 << 34),
+                              "note": "random 64-B reads are counted 1.00x; the guide's under-count applies to wide coalesced streams, i.e. to "
+                                      "the chain/giant share (< 20 % of the fetch total)"}
+    valu, _, _ = pick(d, "SQ_INSTS_VALU", prod)
+    if valu:
+        res["valu_instructions_per_step"] = valu * 64 / steps
+    for key, cname in (("valu_busy_percent", "VALUBusy"), ("salu_busy_percent", "SALUBusy"), ("mem_unit_stalled_percent", "MemUnitStalled"),
+                       ("mean_occupancy_waves_per_cu", "MeanOccupancyPerCU")):
+        v, _, _ = pick(d, cname, prod)
+        if v is not None:
+            res[key] = v
+    i64, _, _ = pick(d, "SQ_INSTS_VALU_INT64", prod)
+    if i64:
+        res["valu_int64_instructions_per_step"] = i64 * 64 / steps
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res)[:600])
+
+
+if __name__ == "__main__":
+    main()
