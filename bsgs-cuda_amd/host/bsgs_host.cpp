@@ -187,7 +187,7 @@ struct Shared {
     Config cfg;
     uint64_t maxnonce = 0;
     Scalar center_big, gstep, start, width;      // p*w ; 4*maxnonce*w ; -pk ; pke-pk
-    bool end_range = false;
+    bool end_range = false, past_end = false;
     Affine addpubg, center, pubadd, start_neg;   // -(2w)G ; -(p*w)G ; -(gstep)G ; -(start)G
     Affine realpub, findpub;
     std::mutex job_mutex;
@@ -199,6 +199,8 @@ struct Shared {
     std::atomic<bool> quit{false}, all_done{false};
     std::atomic<uint64_t> steps_done{0}, tiles_done{0};
     std::atomic<int> gpus_finished{0};
+    std::mutex done_mutex;
+    std::condition_variable done_cv;
     std::mutex inflight_mutex;
     std::vector<Scalar> inflight;                 // per GPU: counter of the oldest tile it has not finished (checkpoint = min, 1_9_7File.pb:3904-3911)
     std::vector<bool> inflight_valid;
@@ -219,7 +221,10 @@ static size_t get_jobs(Shared &S, size_t n, std::vector<Tile> &out)
     hs::Jac cur = hs::to_jac(S.glob_pub);
     Scalar key = S.glob_key;
     for (size_t i = 0; i < n; i++) {
-        if (S.end_range && hs::fe_cmp(key, S.width) > 0) break;              // 1_9_7File.pb:2512-2518
+        // 1_9_7File.pb:2512-2518 tests the counter AFTER the launch: the first tile whose counter exceeds the width is still
+        // searched (a tile reaches 2w*maxnonce - p*w below its counter), then the dispenser closes
+        if (S.past_end) break;
+        if (S.end_range && hs::fe_cmp(key, S.width) > 0) S.past_end = true;
         if (S.cfg.max_tiles && S.tiles_done.load() + out.size() >= S.cfg.max_tiles) break;
         Tile t; t.key = key;
         out.push_back(t);
@@ -416,7 +421,7 @@ static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8
 
 static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
 {
-    const size_t batch = 64;
+    const size_t batch = 32;                      // one launch; a found key stops the job at the next batch boundary
     std::vector<Tile> tiles;
     std::vector<uint8_t> centres;
     std::vector<bsgs_hit_ex> hits(65536);
@@ -440,7 +445,8 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
     }
     { std::lock_guard<std::mutex> lk(S->inflight_mutex); S->inflight_valid[slot] = false; }
     printf("GPU#%d job finished\n", gpu);
-    S->gpus_finished++;
+    { std::lock_guard<std::mutex> lk(S->done_mutex); S->gpus_finished++; }
+    S->done_cv.notify_all();
 }
 
 // ---- Tune (1_9_7File.pb:324-431 prints suggested -t -b -p -w -htsz per GPU from free memory and SM count) ----------
@@ -606,6 +612,7 @@ int main(int argc, char **argv)
         S.glob_key = hs::fe_from_u64(1);
         if (recovery) { if (!hs::fe_from_hex(S.glob_key, rec_cnt)) die("bad counter"); recovery = false; }
         S.glob_pub = hs::point_add(hs::point_add(S.findpub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
+        S.past_end = false;
         S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0;
         const auto t0 = std::chrono::steady_clock::now();
         Scalar one = hs::fe_from_u64(1), two = hs::fe_from_u64(2);
@@ -622,7 +629,7 @@ int main(int argc, char **argv)
             auto last_save = std::chrono::steady_clock::now();
             uint64_t last_steps = 0; auto last_t = t0;
             while (S.gpus_finished.load() < (int)gpus.size()) {
-                std::this_thread::sleep_for(std::chrono::milliseconds(200));
+                { std::unique_lock<std::mutex> lk(S.done_mutex); S.done_cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return S.gpus_finished.load() >= (int)gpus.size(); }); }
                 const auto now = std::chrono::steady_clock::now();
                 if (std::chrono::duration<double>(now - last_t).count() >= 2.0) {       // progress line 5119-5142
                     const uint64_t st = S.steps_done.load();
@@ -637,7 +644,7 @@ int main(int argc, char **argv)
             }
             for (auto &x : th) x.join();
             // drain the checker queue, then stop it
-            for (;;) { { std::lock_guard<std::mutex> lk(S.chk_mutex); if (S.checker.empty()) break; } if (S.quit.load()) break; std::this_thread::sleep_for(std::chrono::milliseconds(10)); }
+            for (;;) { { std::lock_guard<std::mutex> lk(S.chk_mutex); if (S.checker.empty()) break; } if (S.quit.load()) break; std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
             S.all_done = true; S.chk_cv.notify_all();
             for (auto &x : chk) x.join();
         } else { S.winkey = trivial; S.found = true; }

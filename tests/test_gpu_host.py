@@ -139,3 +139,22 @@ def test_config3_style_w34_80bit_range(tmp_path):
                "-pk", "80000000000000000000", "-pke", "ffffffffffffffffffff"], tmp_path, timeout=900)
     assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % key
     assert "17179869184 items" in out
+
+
+def test_key_in_the_last_tile_of_a_range(tmp_path):
+    """1_9_7File.pb:2512-2518 tests the tile counter AFTER the launch, so the first tile whose counter exceeds the range
+    width is still searched; a key just below -pke lives there (a tile reaches 2w*maxnonce - p*w below its counter).
+    (Found by the 1000-key config-4 run: 4 keys near ffff... were missed before the dispenser did the same.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    # -t 64 -b 8 -p 16 -w 16: tile stride 2^31, counters 1 + j*2^31; width 3*2^31 - 5 ends between tile 2 and tile 3
+    start, width = 1, 3 * 2**31 - 5
+    key = start + width - 10
+    run(["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14", "-pb", "%064x%064x" % ecpy.mul(key),
+         "-pk", "%x" % start, "-pke", "%x" % (start + width)], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % key
+    # and a key beyond -pke + one tile is not looked for: the job ends with "Reached end of space"
+    out = run(["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14", "-pb", "%064x%064x" % ecpy.mul(start + width + 3 * 2**31),
+               "-pk", "%x" % start, "-pke", "%x" % (start + width)], tmp_path)
+    assert "Reached end of space" in out and "Found 0 of 1" in out
