@@ -467,6 +467,10 @@ static void tune(int gpu)
     const double wmax = std::log2(3069485950.0);                                     // reference format limit (1_9_7File.pb:4412-4418)
     if (wl > wmax) wl = wmax;
     printf("GPU #%d %s: %d CUs, %.0f MB free -> suggested  -t 256 -b 256 -p 256 -w %.2f -htsz %u\n", gpu, name, cus, fr / 1048576.0, wl, htsz);
+    // beyond the reference's table format (no HT files): 128-byte bucket lines at 8 entries per bucket, built in GPU memory
+    uint32_t eh = 20;
+    while (eh < 32 && (128ull << (eh + 1)) <= budget) eh++;
+    if (eh + 3 > 31) printf("GPU #%d extended table (w above the reference limit): -t 256 -b 256 -p 256 -w %u -htsz %u\n", gpu, std::min(eh + 3, 36u), eh);
     bsgs_dev_close(dev);
 }
 
