@@ -201,31 +201,35 @@ static double expected_overflow_entries(double lambda, unsigned cap, double buck
     return e * buckets;
 }
 
-extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
+static int ext_check(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
 {
     if (!d) return fail(BSGS_ERR_ARG, "null");
     if (!w || w > (1ull << 36) || htsz < 1 || htsz > 32) return fail(BSGS_ERR_ARG, "need 0 < w <= 2^36 and 1 <= htsz <= 32");
     if (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "layout must be BSGS_TABLE_LINES64_LIST or BSGS_TABLE_LINES128_LIST");
-    HIPCHK(hipSetDevice(d->id));
-    bsgs_free_table(d);
-    const int lplog = layout == BSGS_TABLE_LINES128_LIST ? 3 : 2;
-    const unsigned cap_line = (4u << lplog) - 1;
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_ext_overflow_capacity(uint64_t w, uint32_t htsz, uint32_t layout, uint64_t *cap)
+{
+    if (!cap || !w || htsz < 1 || htsz > 32 || (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST)) return fail(BSGS_ERR_ARG, "bad args");
+    const unsigned cap_line = layout == BSGS_TABLE_LINES128_LIST ? 31 : 15;
+    const double buckets = (double)(1ull << htsz);
+    *cap = std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / buckets, cap_line, buckets)) + (1u << 20));
+    return BSGS_OK;
+}
+
+// the builder proper: lines / ovf are device buffers of 2^htsz lines and ovf_cap keys
+static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32x4 *lines, u64 *ovf, uint64_t ovf_cap, uint64_t *ovf_n, uint64_t *overflow_buckets)
+{
     const uint64_t ht_items = 1ull << htsz, line_bytes = 64ull << (lplog - 2);
     // one generation chunk = T threads x pi points; large chunks keep the host-side base points (T per chunk) off the clock
     const uint32_t T = 1u << 16, pi = w > (1ull << 28) ? 4096 : 512;
     const uint64_t chunk = (uint64_t)T * pi;
-    const uint64_t ovf_cap = std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / (double)ht_items, cap_line, (double)ht_items)) + (1u << 20));
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
-    const uint64_t need = ht_items * line_bytes + ovf_cap * 16 + std::min(chunk, w) * 8 + (uint64_t)T * pi * 32 + (64ull << 20);
-    if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table needs %.1f GiB, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
-    u32x4 *lines = nullptr;
-    u64 *ovf = nullptr;
+    const uint64_t need = ovf_cap * 8 + std::min(chunk, w) * 8 + (uint64_t)T * pi * 32 + (64ull << 20);     // sort buffer, keys, chain
+    if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table build needs %.1f GiB of scratch, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
     DevBuf keys, chainb, helperb, basesb, cnt;
-    HIPCHK(hipMalloc(&lines, ht_items * line_bytes));
-    hipError_t e = hipMalloc(&ovf, ovf_cap * 8);
-    if (e != hipSuccess) { (void)hipFree(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
-    struct Guard { u32x4 *&l; u64 *&o; ~Guard() { if (l) (void)hipFree(l); if (o) (void)hipFree(o); } } guard{lines, ovf};
     HIPCHK(hipMemsetAsync(lines, 0, ht_items * line_bytes, d->stream));
     HIPCHK(cnt.alloc(16));
     HIPCHK(hipMemsetAsync(cnt.p, 0, 16, d->stream));
@@ -273,10 +277,56 @@ extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz,
     (void)hipFree(keys.p); keys.p = nullptr;
     int rc = bsgs_sort_u64(d, ovf, h[1]);
     if (rc) return rc;
-    rc = bsgs_install_lines(d, lines, lplog, ovf, h[1], ht_items, w, h[0]);
-    if (rc) return rc;
-    lines = nullptr; ovf = nullptr;                                   // owned by the engine now
+    *ovf_n = h[1]; *overflow_buckets = h[0];
     return BSGS_OK;
+}
+
+extern "C" int bsgs_build_baby_table_ext_device(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout, void *lines_dev, void *ovf_dev,
+                                                uint64_t ovf_cap, uint64_t *ovf_n, uint64_t *overflow_buckets)
+{
+    int rc = ext_check(d, w, htsz, layout);
+    if (rc) return rc;
+    if (!lines_dev || !ovf_dev || !ovf_n || !overflow_buckets) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    return ext_build_into(d, w, htsz, layout == BSGS_TABLE_LINES128_LIST ? 3 : 2, (u32x4 *)lines_dev, (u64 *)ovf_dev, ovf_cap, ovf_n, overflow_buckets);
+}
+
+extern "C" int bsgs_install_table_ext_device(bsgs_dev *d, const void *lines_dev, const void *ovf_dev, uint64_t ovf_n, uint64_t overflow_buckets,
+                                             uint64_t w, uint32_t htsz, uint32_t layout)
+{
+    int rc = ext_check(d, w, htsz, layout);
+    if (rc) return rc;
+    if (!lines_dev || (!ovf_dev && ovf_n)) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    rc = bsgs_install_lines(d, (u32x4 *)lines_dev, layout == BSGS_TABLE_LINES128_LIST ? 3 : 2, (u64 *)ovf_dev, ovf_n, 1ull << htsz, w, overflow_buckets);
+    if (rc) return rc;
+    d->lines_owned = false;                                           // borrowed: the caller keeps both buffers alive
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
+{
+    int rc = ext_check(d, w, htsz, layout);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(d->id));
+    bsgs_free_table(d);
+    const int lplog = layout == BSGS_TABLE_LINES128_LIST ? 3 : 2;
+    const uint64_t ht_items = 1ull << htsz, line_bytes = 64ull << (lplog - 2);
+    uint64_t ovf_cap = 0;
+    rc = bsgs_ext_overflow_capacity(w, htsz, layout, &ovf_cap);
+    if (rc) return rc;
+    size_t fr = 0, tot = 0;
+    HIPCHK(hipMemGetInfo(&fr, &tot));
+    if (ht_items * line_bytes + ovf_cap * 8 > fr) return fail(BSGS_ERR_NOMEM, "extended table needs %.1f GiB, %.1f GiB free", (ht_items * line_bytes + ovf_cap * 8) / 1073741824.0, fr / 1073741824.0);
+    u32x4 *lines = nullptr;
+    u64 *ovf = nullptr;
+    HIPCHK(hipMalloc(&lines, ht_items * line_bytes));
+    hipError_t e = hipMalloc(&ovf, ovf_cap * 8);
+    if (e != hipSuccess) { (void)hipFree(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
+    uint64_t n = 0, ob = 0;
+    rc = ext_build_into(d, w, htsz, lplog, lines, ovf, ovf_cap, &n, &ob);
+    if (rc) { (void)hipFree(lines); (void)hipFree(ovf); return rc; }
+    return bsgs_install_lines(d, lines, lplog, ovf, n, ht_items, w, ob);    // the engine owns both buffers now
 }
 
 static int check_args(bsgs_dev *d, uint64_t w, uint32_t htsz)

@@ -68,9 +68,9 @@ extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
 static void free_table(bsgs_dev *d)
 {
     if (d->csr && d->csr_owned) (void)hipFree(d->csr);
-    if (d->lines) (void)hipFree(d->lines);
-    if (d->ovf) (void)hipFree(d->ovf);
-    d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0;
+    if (d->lines && d->lines_owned) (void)hipFree(d->lines);
+    if (d->ovf && d->lines_owned) (void)hipFree(d->ovf);
+    d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true;
 }
 void bsgs_free_table(bsgs_dev *d) { free_table(d); }
 static void free_g2(bsgs_dev *d)

@@ -37,6 +37,7 @@ struct bsgs_dev {
     u32 *csr = nullptr;         // htGPU image
     bool csr_owned = true;
     u32x4 *lines = nullptr;
+    bool lines_owned = true;    // false: lines / ovf were handed over by bsgs_install_table_ext_device (borrowed)
     u64 *ovf = nullptr;         // "lines + overflow list" formats (no CSR on the device): sorted (bucket << 32 | hash)
     uint64_t ovf_n = 0;
     uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;

@@ -20,7 +20,7 @@ NATIVE_SYMBOLS = [
     "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
-    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_profile_phases",
+    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -84,6 +84,9 @@ def lib():
             "bsgs_build_baby_tables": [vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32],
             "bsgs_build_baby_tables_device": [vp, C.c_uint64, C.c_uint32, vp, vp],
             "bsgs_build_baby_table_ext": [vp, C.c_uint64, C.c_uint32, C.c_uint32],
+            "bsgs_ext_overflow_capacity": [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)],
+            "bsgs_build_baby_table_ext_device": [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+            "bsgs_install_table_ext_device": [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32],
             "bsgs_profile_phases": [vp, u8p, C.c_uint32, C.POINTER(C.c_float)],
         }
         for name, args in sig.items():
@@ -176,6 +179,20 @@ class Device:
     def build_baby_table_ext(self, w, htsz, layout=TABLE_LINES64_LIST):
         """k*G, k = 1..w (w up to 2^36) straight into bucket lines + overflow list on the device (no CSR, no positions)"""
         _chk(self.L.bsgs_build_baby_table_ext(self.h, w, htsz, layout))
+
+    def ext_overflow_capacity(self, w, htsz, layout=TABLE_LINES64_LIST):
+        cap = C.c_uint64(0)
+        _chk(self.L.bsgs_ext_overflow_capacity(w, htsz, layout, C.byref(cap)))
+        return cap.value
+
+    def build_baby_table_ext_device(self, w, htsz, layout, lines_dptr, ovf_dptr, ovf_cap):
+        """build into caller-owned device buffers (source of an RCCL broadcast); returns (ovf_n, overflow_buckets)"""
+        n, ob = C.c_uint64(0), C.c_uint64(0)
+        _chk(self.L.bsgs_build_baby_table_ext_device(self.h, w, htsz, layout, C.c_void_p(lines_dptr), C.c_void_p(ovf_dptr), ovf_cap, C.byref(n), C.byref(ob)))
+        return n.value, ob.value
+
+    def install_table_ext_device(self, lines_dptr, ovf_dptr, ovf_n, overflow_buckets, w, htsz, layout):
+        _chk(self.L.bsgs_install_table_ext_device(self.h, C.c_void_p(lines_dptr), C.c_void_p(ovf_dptr), ovf_n, overflow_buckets, w, htsz, layout))
 
     def table_info(self):
         lay, nb, ov = C.c_uint32(), C.c_uint64(), C.c_uint64()

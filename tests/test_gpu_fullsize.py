@@ -115,3 +115,33 @@ def test_extended_table_w34():
         extra += len(mine) - len(expect)
     assert extra <= 4
     dev.close()
+
+
+def test_extended_table_built_into_caller_memory_and_installed_borrowed():
+    """the RCCL-broadcast route of an extended table (bench.py, N > 1): build into caller-owned device buffers, install
+    them borrowed; must answer exactly like the engine-owned build of the same table"""
+    import pybsgs
+    from pybsgs import ecpy
+    t, b, p, wexp, htsz = 64, 16, 64, 22, 18          # load 16 per bucket: 64-byte lines overflow often, 128-byte ones rarely
+    w = 1 << wexp
+    dev = pybsgs.Device(0)
+    A = ecpy.addpubg(w)
+    dev.generate_g2(A[0], A[1], t, b, p)
+    maxnonce = t * b * p
+    ms = [5 * 2 * w + 77, -(maxnonce * 2 * w) + 12345, w // 3, 17 * 2 * w - w, (maxnonce + 5) * 2 * w + 99]
+    centres = [ecpy.mul(m % N) for m in ms]
+    for lay in (pybsgs.TABLE_LINES64_LIST, pybsgs.TABLE_LINES128_LIST):
+        dev.build_baby_table_ext(w, htsz, lay)
+        want, nw, _ = dev.run(centres, 65536)
+        info = dev.table_info()
+        cap = dev.ext_overflow_capacity(w, htsz, lay)
+        lines = torch.empty((1 << htsz) * (16 if lay == pybsgs.TABLE_LINES64_LIST else 32), dtype=torch.int32, device="cuda:0")
+        ovf = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+        n_ovf, n_over = dev.build_baby_table_ext_device(w, htsz, lay, lines.data_ptr(), ovf.data_ptr(), cap)
+        dev.install_table_ext_device(lines.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
+        assert dev.table_info() == info and n_ovf <= cap
+        got, ng, _ = dev.run(centres, 65536)
+        assert (ng, got) == (nw, want) and nw >= 4
+        for k, m in enumerate(ms):
+            assert set(analytic_hits(m, w, maxnonce)) <= {(c, i) for tile, c, i in got if tile == k}
+    dev.close()
