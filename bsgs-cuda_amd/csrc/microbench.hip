@@ -6,6 +6,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 microbench.hip -o microbench
 // Run  : ./microbench [footprint_MiB ...]
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -205,8 +206,67 @@ __global__ void fill_kernel(uint4 *buf, size_t n)
     for (; i < n; i += stride) buf[i] = make_uint4((u32)i, (u32)(i >> 32), (u32)i * 2654435761u, 7u);
 }
 
+// "power" mode: keep ONE instruction mix running for `secs` seconds so that tools/power_ops.sh can sample rocm-smi next
+// to it; prints the sustained rate (the clock the chip settles at under that mix is part of the answer)
+template <int OP>
+static void sustain(const char *name, int per_iter, double secs, u32 *dout)
+{
+    const int blocks = 256 * 8, threads = 256, iters = 40000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double total_ms = 0, n = 0;
+    while (total_ms < secs * 1e3) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, dout, iters, 2u);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms; n += (double)blocks * threads * iters * 16.0 * per_iter;
+    }
+    printf("{\"bench\":\"sustain\",\"op\":\"%s\",\"seconds\":%.2f,\"Gops_per_s\":%.1f}\n", name, total_ms / 1e3, n / (total_ms * 1e-3) / 1e9);
+}
+
+// sustained cooperative random reads (4 lanes x 16 B = one 64-byte line, or 8 x 16 = 128 B) over `mib` MiB
+template <int LANES_PER>
+static void sustain_gups(double secs, size_t mib, u32 *dout)
+{
+    const size_t bytes = mib << 20;
+    uint4 *buf; CK(hipMalloc(&buf, bytes));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf, bytes / 16);
+    CK(hipDeviceSynchronize());
+    const int threads = 256, blocks = 256 * 8, iters = 4096;
+    const u64 n_gran = bytes / (16 * LANES_PER);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double total_ms = 0, reads = 0;
+    u64 seed = 7;
+    while (total_ms < secs * 1e3) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((gups_coop_kernel<LANES_PER, 8>), dim3(blocks), dim3(threads), 0, 0, (const u32x4 *)buf, n_gran, iters, dout, seed++);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms; reads += (double)blocks * threads * iters * 8 / LANES_PER;
+    }
+    printf("{\"bench\":\"sustain\",\"op\":\"random %d-byte reads over %zu MiB\",\"seconds\":%.2f,\"Greads_per_s\":%.2f}\n", 16 * LANES_PER, mib,
+           total_ms / 1e3, reads / (total_ms * 1e-3) / 1e9);
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 4 && !strcmp(argv[1], "power")) {
+        u32 *dout; CK(hipMalloc(&dout, 256 * 8 * 256 * 4));
+        const int op = atoi(argv[2]); const double secs = atof(argv[3]);
+        switch (op) {
+        case 100: sustain_gups<4>(secs, 16384, dout); break;
+        case 101: sustain_gups<8>(secs, 16384, dout); break;
+        case 102: sustain_gups<4>(secs, 16, dout); break;          // L2-resident footprint
+        case 3: sustain<3>("v_add_u32", 4, secs, dout); break;
+        case 0: sustain<0>("v_mad_u64_u32", 4, secs, dout); break;
+        case 1: sustain<1>("v_mul_lo_u32", 4, secs, dout); break;
+        case 4: sustain<4>("v_fma_f64", 4, secs, dout); break;
+        case 6: sustain<6>("carry_chain_add_co+3addc", 4, secs, dout); break;
+        case 9: sustain<9>("4mad+3addc_pipelined", 7, secs, dout); break;
+        default: printf("unknown op\n"); return 1;
+        }
+        return 0;
+    }
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("{\"device\":\"%s\",\"cus\":%d,\"clock_MHz\":%d,\"mem_GiB\":%.1f}\n", prop.name, prop.multiProcessorCount,
            prop.clockRate / 1000, prop.totalGlobalMem / 1073741824.0);
