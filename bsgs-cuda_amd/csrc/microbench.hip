@@ -248,6 +248,42 @@ static void sustain_gups(double secs, size_t mib, u32 *dout)
            total_ms / 1e3, reads / (total_ms * 1e-3) / 1e9);
 }
 
+// sustained coalesced 16-byte-per-lane reads (a wave reads 1 KiB contiguous) over `mib` MiB
+__global__ void __launch_bounds__(256) stream_kernel(const u32x4 *__restrict__ buf, u64 n16, int iters, u32 *out)
+{
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 acc = 0;
+    for (int k = 0; k < iters; k++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const u32x4 v = buf[i];
+            acc += v.x ^ v.y ^ v.z ^ v.w;
+            i += stride;
+            if (i >= n16) i -= n16;
+        }
+    }
+    if (acc == 0x9abcdef1u) out[0] = acc;
+}
+static void sustain_stream(double secs, size_t mib, u32 *dout)
+{
+    const size_t bytes = mib << 20;
+    uint4 *buf; CK(hipMalloc(&buf, bytes));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, buf, bytes / 16);
+    CK(hipDeviceSynchronize());
+    const int threads = 256, blocks = 256 * 8, iters = 2048;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double total_ms = 0, rd = 0;
+    while (total_ms < secs * 1e3) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(stream_kernel, dim3(blocks), dim3(threads), 0, 0, (const u32x4 *)buf, (u64)(bytes / 16), iters, dout);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms; rd += (double)blocks * threads * iters * 8 * 16;
+    }
+    printf("{\"bench\":\"sustain\",\"op\":\"coalesced reads over %zu MiB\",\"seconds\":%.2f,\"GB_per_s\":%.1f}\n", mib, total_ms / 1e3, rd / (total_ms * 1e-3) / 1e9);
+}
+
 int main(int argc, char **argv)
 {
     if (argc >= 4 && !strcmp(argv[1], "power")) {
@@ -257,6 +293,8 @@ int main(int argc, char **argv)
         case 100: sustain_gups<4>(secs, 16384, dout); break;
         case 101: sustain_gups<8>(secs, 16384, dout); break;
         case 102: sustain_gups<4>(secs, 16, dout); break;          // L2-resident footprint
+        case 103: sustain_stream(secs, 16384, dout); break;
+        case 104: sustain_stream(secs, 16, dout); break;
         case 3: sustain<3>("v_add_u32", 4, secs, dout); break;
         case 0: sustain<0>("v_mad_u64_u32", 4, secs, dout); break;
         case 1: sustain<1>("v_mul_lo_u32", 4, secs, dout); break;
