@@ -172,21 +172,6 @@ static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img,
     return BSGS_OK;
 }
 
-int bsgs_sort_u64(bsgs_dev *d, u64 *keys, uint64_t n)
-{
-    if (n < 2) return BSGS_OK;
-    DevBuf alt, tmp;
-    HIPCHK(alt.alloc(n * 8));
-    size_t tmp_bytes = 0;
-    rocprim::double_buffer<u64> db(keys, alt.as<u64>());
-    HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t)n, 0u, 64u, d->stream));
-    HIPCHK(tmp.alloc(tmp_bytes));
-    HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, db, (size_t)n, 0u, 64u, d->stream));
-    if (db.current() != keys) HIPCHK(hipMemcpyAsync(keys, db.current(), n * 8, hipMemcpyDeviceToDevice, d->stream));
-    HIPCHK(hipStreamSynchronize(d->stream));
-    return BSGS_OK;
-}
-
 // expected number of entries beyond `cap` per bucket for Poisson(lambda) loads, times the number of buckets
 static double expected_overflow_entries(double lambda, unsigned cap, double buckets)
 {
@@ -204,30 +189,40 @@ static double expected_overflow_entries(double lambda, unsigned cap, double buck
 static int ext_check(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
 {
     if (!d) return fail(BSGS_ERR_ARG, "null");
-    if (!w || w > (1ull << 36) || htsz < 1 || htsz > 32) return fail(BSGS_ERR_ARG, "need 0 < w <= 2^36 and 1 <= htsz <= 32");
+    if (!w || w > (1ull << 36) || htsz < 1 || htsz > 31) return fail(BSGS_ERR_ARG, "need 0 < w <= 2^36 and 1 <= htsz <= 31");
     if (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "layout must be BSGS_TABLE_LINES64_LIST or BSGS_TABLE_LINES128_LIST");
     return BSGS_OK;
 }
 
-extern "C" int bsgs_ext_overflow_capacity(uint64_t w, uint32_t htsz, uint32_t layout, uint64_t *cap)
+// upper estimate of the entries that will not fit their line (Poisson loads), with slack
+static uint64_t ext_list_capacity(uint64_t w, uint32_t htsz, uint32_t layout)
 {
-    if (!cap || !w || htsz < 1 || htsz > 32 || (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST)) return fail(BSGS_ERR_ARG, "bad args");
     const unsigned cap_line = layout == BSGS_TABLE_LINES128_LIST ? 31 : 15;
     const double buckets = (double)(1ull << htsz);
-    *cap = std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / buckets, cap_line, buckets)) + (1u << 20));
+    return std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / buckets, cap_line, buckets)) + (1u << 20));
+}
+
+extern "C" int bsgs_ext_overflow_capacity(uint64_t w, uint32_t htsz, uint32_t layout, uint64_t *cap)
+{
+    if (!cap || !w || htsz < 1 || htsz > 31 || (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST)) return fail(BSGS_ERR_ARG, "bad args");
+    *cap = bsgs_ovf_slots(ext_list_capacity(w, htsz, layout));
     return BSGS_OK;
 }
 
-// the builder proper: lines / ovf are device buffers of 2^htsz lines and ovf_cap keys
-static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32x4 *lines, u64 *ovf, uint64_t ovf_cap, uint64_t *ovf_n, uint64_t *overflow_buckets)
+// the builder proper: lines = 2^htsz lines, ovf_table = ovf_slots u64 (both device memory)
+static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32x4 *lines, u64 *ovf_table, uint64_t ovf_slots, uint64_t *ovf_n, uint64_t *overflow_buckets)
 {
+    const uint64_t ovf_cap = ovf_slots / 2;                           // the hash set takes at most that many keys
+    DevBuf listb;
+    HIPCHK(listb.alloc(ovf_cap * 8));
+    u64 *ovf = listb.as<u64>();
     const uint64_t ht_items = 1ull << htsz, line_bytes = 64ull << (lplog - 2);
     // one generation chunk = T threads x pi points; large chunks keep the host-side base points (T per chunk) off the clock
     const uint32_t T = 1u << 16, pi = w > (1ull << 28) ? 4096 : 512;
     const uint64_t chunk = (uint64_t)T * pi;
     size_t fr = 0, tot = 0;
     HIPCHK(hipMemGetInfo(&fr, &tot));
-    const uint64_t need = ovf_cap * 8 + std::min(chunk, w) * 8 + (uint64_t)T * pi * 32 + (64ull << 20);     // sort buffer, keys, chain
+    const uint64_t need = std::min(chunk, w) * 8 + (uint64_t)T * pi * 32 + (64ull << 20);     // keys, chain
     if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table build needs %.1f GiB of scratch, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
     DevBuf keys, chainb, helperb, basesb, cnt;
     HIPCHK(hipMemsetAsync(lines, 0, ht_items * line_bytes, d->stream));
@@ -275,9 +270,9 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
     if (h[1] > ovf_cap) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries, capacity %llu", h[1], (unsigned long long)ovf_cap);
     (void)hipFree(chainb.p); chainb.p = nullptr;
     (void)hipFree(keys.p); keys.p = nullptr;
-    int rc = bsgs_sort_u64(d, ovf, h[1]);
+    int rc = bsgs_ovf_fill(d, ovf, h[1], ovf_table, ovf_slots);
     if (rc) return rc;
-    *ovf_n = h[1]; *overflow_buckets = h[0];
+    *ovf_n = ovf_slots; *overflow_buckets = h[0];
     return BSGS_OK;
 }
 
@@ -296,7 +291,8 @@ extern "C" int bsgs_install_table_ext_device(bsgs_dev *d, const void *lines_dev,
 {
     int rc = ext_check(d, w, htsz, layout);
     if (rc) return rc;
-    if (!lines_dev || (!ovf_dev && ovf_n)) return fail(BSGS_ERR_ARG, "null");
+    if (!lines_dev || !ovf_dev) return fail(BSGS_ERR_ARG, "null");
+    if (ovf_n < 2 || (ovf_n & (ovf_n - 1))) return fail(BSGS_ERR_ARG, "ovf_n must be the slot count returned by the builder (a power of two)");
     HIPCHK(hipSetDevice(d->id));
     rc = bsgs_install_lines(d, (u32x4 *)lines_dev, layout == BSGS_TABLE_LINES128_LIST ? 3 : 2, (u64 *)ovf_dev, ovf_n, 1ull << htsz, w, overflow_buckets);
     if (rc) return rc;

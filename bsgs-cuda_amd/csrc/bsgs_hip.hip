@@ -294,12 +294,35 @@ static int build_lines(bsgs_dev *d, uint32_t layout, bool with_list)
     d->overflow = h[0];
     d->layout = layout;
     if (with_list) {
-        int rc = bsgs_sort_u64(d, list, cap);
-        if (rc) { (void)hipFree(list); return rc; }
-        d->ovf = list; d->ovf_n = cap;
+        const uint64_t slots = bsgs_ovf_slots(cap);
+        u64 *table = nullptr;
+        if (hipMalloc(&table, slots * 8) != hipSuccess) { (void)hipFree(list); return fail(BSGS_ERR_NOMEM, "overflow set: %llu slots", (unsigned long long)slots); }
+        int rc = bsgs_ovf_fill(d, list, cap, table, slots);
+        (void)hipFree(list);
+        if (rc) { (void)hipFree(table); return rc; }
+        d->ovf = table; d->ovf_n = slots;
         if (d->csr && d->csr_owned) (void)hipFree(d->csr);
         d->csr = nullptr;                                               // borrowed images stay with the caller
     }
+    return BSGS_OK;
+}
+
+uint64_t bsgs_ovf_slots(uint64_t entries)
+{
+    uint64_t s = 2;
+    while (s < 2 * entries) s <<= 1;
+    return s;
+}
+int bsgs_ovf_fill(bsgs_dev *d, const u64 *list, uint64_t n, u64 *table, uint64_t slots)
+{
+    if (slots < 2 || (slots & (slots - 1)) || 2 * n > slots) return fail(BSGS_ERR_ARG, "overflow set: %llu keys do not fit %llu slots at load 1/2", (unsigned long long)n, (unsigned long long)slots);
+    HIPCHK(hipMemsetAsync(table, 0xFF, slots * 8, d->stream));
+    if (n) {
+        const int blocks = (int)std::min<uint64_t>((n + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(ovf_insert_kernel, dim3(blocks), dim3(256), 0, d->stream, list, n, table, slots - 1);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(d->stream));
     return BSGS_OK;
 }
 

@@ -38,8 +38,8 @@ struct bsgs_dev {
     bool csr_owned = true;
     u32x4 *lines = nullptr;
     bool lines_owned = true;    // false: lines / ovf were handed over by bsgs_install_table_ext_device (borrowed)
-    u64 *ovf = nullptr;         // "lines + overflow list" formats (no CSR on the device): sorted (bucket << 32 | hash)
-    uint64_t ovf_n = 0;
+    u64 *ovf = nullptr;         // "lines + overflow list" formats (no CSR on the device): hash set of (bucket << 32 | hash)
+    uint64_t ovf_n = 0;         // slots (power of two)
     uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
     uint32_t layout = 0;        // probe layout: 1 csr, 2 lines64, 3 lines128 (ovf != NULL: reported as 4 / 5)
     u32 *hitbuf = nullptr;      // device
@@ -57,7 +57,8 @@ struct bsgs_dev {
 
 // shared between the translation units of the library
 void bsgs_free_table(bsgs_dev *d);
-int bsgs_sort_u64(bsgs_dev *d, u64 *keys, uint64_t n);      // in place, ascending (rocPRIM radix sort; baby_builder.hip)
+uint64_t bsgs_ovf_slots(uint64_t entries);                   // size of the overflow hash set for `entries` keys (power of two, load <= 1/2)
+int bsgs_ovf_fill(bsgs_dev *d, const u64 *list, uint64_t n, u64 *table, uint64_t slots);   // table := hash set of list[0..n)
 // hand a finished "lines + overflow list" table to the engine (it becomes the owner of both buffers)
 int bsgs_install_lines(bsgs_dev *d, u32x4 *lines, int lplog, u64 *ovf, uint64_t ovf_n, uint64_t ht_items, uint64_t w,
                        uint64_t overflow_buckets);

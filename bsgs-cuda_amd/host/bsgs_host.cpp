@@ -409,8 +409,10 @@ static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8
     if (S.cfg.ext) {
         const auto t0 = std::chrono::steady_clock::now();
         const double load = (double)S.cfg.w / (double)(1ull << S.cfg.htsz);
+        // 64-byte lines up to ~9 entries per bucket (the over-full 1 % go through the overflow set: measured faster AND half
+        // the memory of 128-byte lines at -w 34 -htsz 31); beyond that 128-byte lines if they fit
         const bool fits128 = (128ull << S.cfg.htsz) + (24ull << 30) < fr;
-        CK(bsgs_build_baby_table_ext(dev, S.cfg.w, S.cfg.htsz, load > 5.0 && fits128 ? BSGS_TABLE_LINES128_LIST : BSGS_TABLE_LINES64_LIST));
+        CK(bsgs_build_baby_table_ext(dev, S.cfg.w, S.cfg.htsz, load > 9.0 && fits128 ? BSGS_TABLE_LINES128_LIST : BSGS_TABLE_LINES64_LIST));
         uint32_t lay = 0; uint64_t bytes = 0, ovf = 0;
         CK(bsgs_table_info(dev, &lay, &bytes, &ovf));
         printf("GPU #%d extended table: %llu items, %.1f GiB in memory, %llu over-full buckets, built in %.1fs\n", gpu, (unsigned long long)S.cfg.w,
@@ -467,9 +469,9 @@ static void tune(int gpu)
     const double wmax = std::log2(3069485950.0);                                     // reference format limit (1_9_7File.pb:4412-4418)
     if (wl > wmax) wl = wmax;
     printf("GPU #%d %s: %d CUs, %.0f MB free -> suggested  -t 256 -b 256 -p 256 -w %.2f -htsz %u\n", gpu, name, cus, fr / 1048576.0, wl, htsz);
-    // beyond the reference's table format (no HT files): 128-byte bucket lines at 8 entries per bucket, built in GPU memory
+    // beyond the reference's table format (no HT files): 64-byte bucket lines at 8 entries per bucket, built in GPU memory
     uint32_t eh = 20;
-    while (eh < 32 && (128ull << (eh + 1)) <= budget) eh++;
+    while (eh < 31 && (64ull << (eh + 1)) <= budget) eh++;
     if (eh + 3 > 31) printf("GPU #%d extended table (w above the reference limit): -t 256 -b 256 -p 256 -w %u -htsz %u\n", gpu, std::min(eh + 3, 36u), eh);
     bsgs_dev_close(dev);
 }
