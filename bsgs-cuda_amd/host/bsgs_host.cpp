@@ -498,8 +498,64 @@ static void save_checkpoint(Shared &S)
     rename(tmp.c_str(), dst.c_str());
 }
 
+// ---- -selftest: the host-side logic that needs no GPU (CPU test tier, tests/test_host_logic.py) ------------------------
+// prints "key value" lines: SHA1, the configuration fingerprint, host EC arithmetic, public-key parsing, the dispenser
+// sequence and the table-free resolver, each for the inputs given on the command line
+static int selftest(int argc, char **argv)
+{
+    std::vector<std::string> a(argv + 2, argv + argc);
+    auto pt = [](const Affine &q) { return q.inf ? std::string("inf") : hs::fe_to_hex(q.x) + " " + hs::fe_to_hex(q.y); };
+    for (size_t i = 0; i < a.size(); i++) {
+        if (a[i] == "sha1" && i + 1 < a.size()) printf("sha1 %s\n", sha1_hex(a[++i]).c_str());
+        else if (a[i] == "fingerprint") {
+            Config c; c.t = 256; c.b = 88; c.p = 130; c.w = 982162051; c.pk = "8000000000000000"; c.pke = "ffffffffffffffff"; c.htsz = 28;
+            printf("fingerprint %s\n", fingerprint(c).c_str());
+        } else if (a[i] == "mul" && i + 1 < a.size()) {
+            Scalar k; if (!hs::fe_from_hex(k, a[++i])) return 2;
+            printf("mul %s\n", pt(hs::point_mul(hs::G, k)).c_str());
+        } else if (a[i] == "parse" && i + 1 < a.size()) {
+            Affine q; const bool ok = hs::parse_pubkey(q, cut_hex(a[++i])) && hs::on_curve(q);
+            printf("parse %s %s\n", ok ? pt(q).c_str() : "invalid", ok ? hs::compress_pubkey(q).c_str() : "");
+        } else if (a[i] == "multiples" && i + 2 < a.size()) {                 // n multiples of k*G through the batched normalisation
+            Scalar k; if (!hs::fe_from_hex(k, a[++i])) return 2;
+            const size_t n = (size_t)atoi(a[++i].c_str());
+            const std::vector<Affine> v = hs::multiples(hs::point_mul(hs::G, k), n);
+            printf("multiples %s\n", pt(v.back()).c_str());
+        } else if (a[i] == "jobs" && i + 5 < a.size()) {                     // dispenser: t b p w n -> counters and centres of n tiles
+            Shared S;
+            S.cfg.t = (uint32_t)atoi(a[i + 1].c_str()); S.cfg.b = (uint32_t)atoi(a[i + 2].c_str()); S.cfg.p = (uint32_t)atoi(a[i + 3].c_str());
+            S.cfg.w = strtoull(a[i + 4].c_str(), nullptr, 10);
+            const size_t n = (size_t)atoi(a[i + 5].c_str());
+            Affine pub; if (!hs::parse_pubkey(pub, cut_hex(a[i + 6])) ) return 2;
+            i += 6;
+            S.maxnonce = (uint64_t)S.cfg.t * S.cfg.b * S.cfg.p;
+            S.center_big = hs::sc_from_u128((hs::u128)S.cfg.p * S.cfg.w);
+            S.center = hs::affine_neg(hs::point_mul(hs::G, S.center_big));
+            S.gstep = hs::sc_mul_small(hs::sc_from_u128((hs::u128)S.maxnonce * S.cfg.w), 4);
+            S.pubadd = hs::affine_neg(hs::point_mul(hs::G, S.gstep));
+            S.glob_key = hs::fe_from_u64(1);
+            S.glob_pub = hs::point_add(hs::point_add(pub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
+            std::vector<Tile> tiles;
+            get_jobs(S, n, tiles);
+            for (const Tile &t : tiles) printf("job %s %s\n", hs::fe_to_hex(t.key).c_str(), pt(t.pub).c_str());
+        } else if (a[i] == "minibsgs" && i + 2 < a.size()) {                 // w (decimal), then hex scalars m: all b' <= w with x(b'G) = x(mG)
+            const uint64_t w = strtoull(a[++i].c_str(), nullptr, 10);
+            MiniBsgs mb; mb.build(w, 4);
+            printf("minibsgs_bits %u\n", mb.mb);
+            for (++i; i < a.size(); i++) {
+                Scalar m; if (!hs::fe_from_hex(m, a[i])) return 2;
+                std::string out;
+                for (uint64_t b : mb.find(hs::point_mul(hs::G, m), w)) out += " " + std::to_string(b);
+                printf("find %s%s\n", a[i].c_str(), out.c_str());
+            }
+        } else { fprintf(stderr, "selftest: unknown item %s\n", a[i].c_str()); return 2; }
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && std::string(argv[1]) == "-selftest") return selftest(argc, argv);
     printf("BSGS MI355X (drop-in for bsgscudaHT 1.9.7-file0) on %s\n", bsgs_version());
     Shared S;
     S.cfg = parse_args(argc, argv);

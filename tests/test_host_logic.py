@@ -1,0 +1,91 @@
+"""CPU tier: the C++ host's GPU-independent logic (bsgs-cuda_amd/host/bsgs_host.cpp -selftest) against hashlib and plain
+Python integers: SHA1 / configuration fingerprint (currentwork.txt, 1_9_7File.pb:4635-4636), host EC arithmetic
+(csrc/host_secp.h), public-key parsing, the tile dispenser (GetJob, 1_9_7File.pb:2077-2092, 5046-5064) and the table-free
+resolver of the extended mode."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "bsgs-cuda_amd", "build", "bsgs_mi355x")
+sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+
+N = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+def selftest(*items):
+    if not os.path.exists(EXE):
+        pytest.skip("host binary not built (run __graft_entry__.build())")
+    res = subprocess.run([EXE, "-selftest"] + [str(x) for x in items], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    return [l.split() for l in res.stdout.splitlines()]
+
+
+def pt_hex(p):
+    return ["%064x" % p[0], "%064x" % p[1]]
+
+
+def test_sha1_and_fingerprint():
+    msgs = ["abc", "a" * 55, "b" * 56, "c" * 64, "Thequickbrownfoxjumpsoverthelazydog" * 5]
+    out = selftest(*[x for m in msgs for x in ("sha1", m)])
+    assert [o[1] for o in out] == [hashlib.sha1(m.encode()).hexdigest() for m in msgs]
+    # Str(t)+Str(b)+Str(p)+Str(w)+pk+pke+Str(htsz)
+    fp = selftest("fingerprint")[0][1]
+    assert fp == hashlib.sha1(b"25688130982162051" + b"8000000000000000" + b"ffffffffffffffff" + b"28").hexdigest()
+
+
+def test_host_ec_arithmetic_matches_python_ints():
+    from pybsgs import ecpy
+    ks = [1, 2, 3, 0x1E9AD, 2**64 - 1, 2**128 + 12345, 2**255 + 7, N - 1, N - 2, 0xF7051F27B09112D4]
+    out = selftest(*[x for k in ks for x in ("mul", "%x" % k)])
+    assert [o[1:] for o in out] == [pt_hex(ecpy.mul(k)) for k in ks]
+    out = selftest("multiples", "5", "1000", "multiples", "%x" % (N - 3), "257")
+    assert out[0][1:] == pt_hex(ecpy.mul(5000)) and out[1][1:] == pt_hex(ecpy.mul((N - 3) * 257 % N))
+
+
+def test_pubkey_parsing():
+    from pybsgs import ecpy
+    x, y = ecpy.mul(0x16f7027bbf8454a5c)
+    comp = ("03" if y & 1 else "02") + "%064x" % x
+    other = ("02" if y & 1 else "03") + "%064x" % x
+    unc = "04%064x%064x" % (x, y)
+    raw = "%064x%064x" % (x, y)
+    out = selftest("parse", comp, "parse", other, "parse", unc, "parse", raw, "parse", "02" + "%064x" % 5, "parse", "04" + "11" * 64)
+    assert out[0][1:] == pt_hex((x, y)) + [comp]
+    assert out[1][1:] == pt_hex((x, ecpy.P - y)) + [other]
+    assert out[2][1:] == pt_hex((x, y)) + [comp] and out[3][1:] == pt_hex((x, y)) + [comp]
+    assert out[4][1] == "invalid" and out[5][1] == "invalid"        # x = 5 is not on the curve; random bytes are not a point
+
+
+def test_dispenser_sequence():
+    """cnt_j = 1 + j * 4*maxnonce*w ;  centre_j = pub - cnt_j*G - (p*w)*G   """
+    from pybsgs import ecpy
+    t, b, p, w, n = 64, 8, 16, 65536, 7
+    key = 0x1E9AD
+    pub = ecpy.mul(key)
+    out = selftest("jobs", t, b, p, w, n, "%064x%064x" % pub)
+    assert len(out) == n
+    gstep = 4 * t * b * p * w
+    for j, o in enumerate(out):
+        cnt = 1 + j * gstep
+        assert int(o[1], 16) == cnt
+        assert o[2:] == pt_hex(ecpy.mul((key - cnt - p * w) % N))
+
+
+def test_table_free_resolver():
+    """MiniBsgs.find(m*G, w): every b' in [1, w] with x(b'G) = x(mG), i.e. b' = m or b' = n - m when in range"""
+    w = 1 << 20
+    ms = [1, 77, w, w - 1, 524289, (1 << 15) + 1, N - 1, N - 77, N - w, w + 1, w + 5, 2 * w, N - w - 1, 0x123456789ABCDEF]
+    out = selftest("minibsgs", w, *["%x" % m for m in ms])
+    assert out[0] == ["minibsgs_bits", "15"]
+    for m, o in zip(ms, out[1:]):
+        expect = sorted({b for b in (m, N - m) if 1 <= b <= w})
+        assert [int(v) for v in o[2:]] == expect, hex(m)
+    w = 3000000                                   # not a power of two
+    ms = [w, w - 1, w + 1, 2999999, 1500000, N - w]
+    out = selftest("minibsgs", w, *["%x" % m for m in ms])
+    for m, o in zip(ms, out[1:]):
+        assert [int(v) for v in o[2:]] == sorted({b for b in (m, N - m) if 1 <= b <= w}), hex(m)
