@@ -367,3 +367,33 @@ def test_all_kernel_variants_agree_with_oracle(O, small_fx, variant, streams):
         h, _ = d.step(int(tl["px"], 16), int(tl["py"], 16))
         assert [list(x) for x in h] == tl["hits"]
     d.close()
+
+
+def test_error_behaviour_of_the_c_abi(small_fx):
+    """every entry point returns 0 or a negative code with a text from bsgs_last_error(); nothing falls back, nothing
+    throws across the boundary (the reference pattern is exit("error <call>-<code>"), 1_9_7File.pb:2195-2197)"""
+    import pybsgs
+    d = pybsgs.Device(0)
+    fx = small_fx
+    Pt = (int(fx["tiles"][0]["px"], 16), int(fx["tiles"][0]["py"], 16))
+    with pytest.raises(pybsgs.BsgsError, match="giants|g2|table|state"):
+        d.step(*Pt)                                                   # nothing uploaded yet
+    d.upload_g2(bytes.fromhex(fx["g2"]), fx["t"], fx["b"], fx["p"])
+    with pytest.raises(pybsgs.BsgsError):
+        d.step(*Pt)                                                   # giants but no table
+    with pytest.raises(pybsgs.BsgsError, match="power of two"):
+        d.upload_htgpu(bytes.fromhex(fx["htgpu"]), (1 << fx["htsz"]) - 1, fx["w"], 1)
+    with pytest.raises(pybsgs.BsgsError, match="layout"):
+        d.upload_htgpu(bytes.fromhex(fx["htgpu"]), 1 << fx["htsz"], fx["w"], 9)
+    with pytest.raises(pybsgs.BsgsError):
+        d.build_baby_table_ext(1 << 10, 8, 2)                         # the direct builder only makes the list formats
+    with pytest.raises(pybsgs.BsgsError):
+        d.build_baby_table_ext(1 << 37, 31, 4)                        # beyond 2^36
+    with pytest.raises(pybsgs.BsgsError):
+        d.upload_g2(bytes.fromhex(fx["g2"]), 0, fx["b"], fx["p"])
+    # and the device still works after the failures
+    d.upload_g2(bytes.fromhex(fx["g2"]), fx["t"], fx["b"], fx["p"])
+    d.upload_htgpu(bytes.fromhex(fx["htgpu"]), 1 << fx["htsz"], fx["w"], 2)
+    hits, n = d.step(*Pt)
+    assert [list(h) for h in hits] == fx["tiles"][0]["hits"]
+    d.close()
