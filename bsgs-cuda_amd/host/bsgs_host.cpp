@@ -720,7 +720,7 @@ int main(int argc, char **argv)
             f << l1 << "\r\n" << l2 << "\r\n";
             finditems++;
         } else printf("\nReached end of space\n");
-        printf("Job time %.1fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)S.tiles_done.load(), (double)S.steps_done.load());
+        printf("Job time %.2fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)S.tiles_done.load(), (double)S.steps_done.load());
     }
     for (bsgs_dev *d : devs) bsgs_dev_close(d);
     printf("Found %d of %zu\n", finditems, pubs.size());
