@@ -397,3 +397,28 @@ def test_error_behaviour_of_the_c_abi(small_fx):
     hits, n = d.step(*Pt)
     assert [list(h) for h in hits] == fx["tiles"][0]["hits"]
     d.close()
+
+
+@pytest.mark.parametrize("layout", [1, 2, 4])
+def test_odd_chain_length_takes_the_per_giant_kernel(dev, O, layout):
+    """-p is even on the reference's command line (1_9_7File.pb:4616-4618) but the C-ABI accepts any p: an odd chain cannot be
+    pair-batched, the engine falls back to the per-giant kernel (and its full-size chain scratch)"""
+    t, b, p, w, htsz = 64, 3, 7, 1 << 14, 11
+    g2, gpu, centres = _planted_case(O, 4242, t, b, p, w, htsz, 12, 3)
+    dev.upload_g2(g2, t, b, p)
+    dev.upload_htgpu(gpu, 1 << htsz, w, layout)
+    for Pt in centres:
+        ref, nref = O.tile_ref(Pt, g2, t, b, p, gpu, htsz, 0, 65536)
+        hits, n = dev.step(Pt[0], Pt[1], 65536)
+        assert (n, hits) == (nref, ref) and nref >= 12
+    # switching back to an even chain on the same device re-sizes the scratch correctly
+    t, b, p = 64, 3, 8
+    g2, gpu, centres = _planted_case(O, 4243, t, b, p, w, htsz, 12, 2)
+    dev.upload_g2(g2, t, b, p)
+    dev.upload_htgpu(gpu, 1 << htsz, w, layout)
+    hits, n, _ = dev.run(centres, 65536)
+    want = []
+    for k, Pt in enumerate(centres):
+        r, _ = O.tile_ref(Pt, g2, t, b, p, gpu, htsz, 0, 65536)
+        want += [(k, c, i) for c, i in r]
+    assert hits == want
