@@ -423,7 +423,7 @@ static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8
 
 static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
 {
-    const size_t batch = 32;                      // one launch; a found key stops the job at the next batch boundary
+    const size_t batch = 48;                      // one launch; a found key stops the job at the next batch boundary
     std::vector<Tile> tiles;
     std::vector<uint8_t> centres;
     std::vector<bsgs_hit_ex> hits(65536);
