@@ -28,7 +28,7 @@ def pick(d, counter, kernel_sub, exclude=None):
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 30
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 48 << 25           # the default launch: 48 tiles of 2^25 giant steps
     prod = ", false>"                                   # production instantiation (PHASE_PROBE = false)
     fetch, nf, kname = pick(d, "FETCH_SIZE", "giant_", None)
     fetch, nf, kname = pick(d, "FETCH_SIZE", prod)
