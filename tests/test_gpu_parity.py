@@ -422,3 +422,27 @@ def test_odd_chain_length_takes_the_per_giant_kernel(dev, O, layout):
         r, _ = O.tile_ref(Pt, g2, t, b, p, gpu, htsz, 0, 65536)
         want += [(k, c, i) for c, i in r]
     assert hits == want
+
+
+def test_hit_buffer_overflow_is_reported_not_hidden(dev, O):
+    """more hits than the caller's buffer: the total is still reported, the first max_hits of the sorted list are
+    returned and the call says BSGS_ERR_OVERFLOW (the reference's buffer holds 240 records per launch, 1_9_7File.pb:2209)"""
+    import ctypes as C
+    import pybsgs
+    t, b, p, w, htsz = 64, 8, 32, 1 << 22, 2            # 2^20 entries per bucket: ~8 hash collisions per tile
+    g2 = O.build_g2(t, b, p, w)
+    keys = np.frombuffer(np.random.default_rng(5).bytes(8 * w), dtype=np.uint64)
+    gpu, _ = O.pack_tables_from_keys(keys, htsz)
+    dev.upload_g2(g2, t, b, p)
+    dev.upload_htgpu(gpu, 1 << htsz, w, 4)
+    Pt = O.pt_mul(0xABCDEF123456789)
+    ref, nref = O.tile_ref(Pt, g2, t, b, p, gpu, htsz, 0, 65536)
+    assert nref >= 4
+    hits = (pybsgs.Hit * 2)()
+    n = C.c_uint32()
+    rc = dev.L.bsgs_step(dev.h, pybsgs.le32(Pt[0]), pybsgs.le32(Pt[1]), hits, 2, C.byref(n))
+    assert rc == pybsgs.ERR_OVERFLOW and n.value == nref
+    assert [(hits[i].code, hits[i].idx) for i in range(2)] == ref[:2]
+    assert b"hits" in dev.L.bsgs_last_error()
+    got, n2 = dev.step(Pt[0], Pt[1], 65536)             # the counter was reset: the next call is complete again
+    assert (n2, got) == (nref, ref)
