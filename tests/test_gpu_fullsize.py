@@ -145,3 +145,41 @@ def test_extended_table_built_into_caller_memory_and_installed_borrowed():
         for k, m in enumerate(ms):
             assert set(analytic_hits(m, w, maxnonce)) <= {(c, i) for tile, c, i in got if tile == k}
     dev.close()
+
+
+def test_gpu_built_tables_pass_the_reference_verifiers_at_config2_size():
+    """The reference checks its tables structurally (1_9_7File.pb:2797-2805, 2911-2912): every k*G, k in
+    [1, w], is found in htCPU with position k-1, and every bucket is ascending.  Same checks on the GPU-built images at
+    BASELINE config 2 size (-w 26 -htsz 25), on the device with torch, plus a spot check against plain Python integers."""
+    import random
+    import pybsgs
+    from pybsgs import ecpy
+    wexp, htsz = 26, 25
+    w, items = 1 << wexp, 1 << htsz
+    dev = pybsgs.Device(0)
+    g = torch.empty(items + 1 + w, dtype=torch.int32, device="cuda:0")
+    c = torch.empty(items + 1 + 2 * w, dtype=torch.int32, device="cuda:0")
+    dev.build_baby_tables_device(w, htsz, g.data_ptr(), c.data_ptr())
+    u32 = lambda t: t.to(torch.int64) & 0xFFFFFFFF                                   # noqa: E731
+    starts = u32(g[: items + 1])
+    assert int(starts[0]) == 0 and int(starts[-1]) == w and bool((starts[1:] >= starts[:-1]).all())
+    assert torch.equal(c[: items + 1], g[: items + 1])                               # same header in both files
+    counts = starts[1:] - starts[:-1]
+    bucket = torch.repeat_interleave(torch.arange(items, device="cuda:0"), counts)
+    hashes = u32(g[items + 1:])
+    key = (bucket << 32) | hashes
+    assert bool((key[1:] >= key[:-1]).all())                                          # ascending inside every bucket
+    pairs = c[items + 1:].view(w, 2)
+    assert torch.equal(u32(pairs[:, 0]), hashes)                                      # htCPU carries the same hashes ...
+    pos = u32(pairs[:, 1])
+    assert torch.equal(torch.sort(pos).values, torch.arange(w, device="cuda:0"))      # ... and every position exactly once
+    # load statistics of a uniform hash: mean 2, P(count > 15) negligible
+    assert int(counts.max()) < 24 and abs(float(counts.float().mean()) - 2.0) < 1e-6
+    rnd = random.Random(26)
+    for k in [1, 2, w, w - 1, w // 2] + [rnd.randrange(1, w + 1) for _ in range(40)]:
+        x = ecpy.mul(k)[0]
+        b, h = x & (items - 1), (x >> 32) & 0xFFFFFFFF
+        lo, hi = int(starts[b]), int(starts[b + 1])
+        seg_h, seg_p = hashes[lo:hi].tolist(), pos[lo:hi].tolist()
+        assert (h, k - 1) in list(zip(seg_h, seg_p)), k
+    dev.close()
