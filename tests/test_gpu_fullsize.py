@@ -183,3 +183,24 @@ def test_gpu_built_tables_pass_the_reference_verifiers_at_config2_size():
         seg_h, seg_p = hashes[lo:hi].tolist(), pos[lo:hi].tolist()
         assert (h, k - 1) in list(zip(seg_h, seg_p)), k
     dev.close()
+
+
+def test_gpu_generated_giants_at_full_geometry():
+    """the reference verifies G2[i] == (i+1)*ADDPUBG after loading the giants (1_9_7File.pb:1543-1556); same check on the
+    2^24 giants of -t 256 -b 256 -p 256 built by the GPU generator, read back in the reference's file layout"""
+    import random
+    import oracle_lib as O
+    import pybsgs
+    from pybsgs import ecpy
+    O.lib()
+    t, b, p, w = 256, 256, 256, 1 << 30
+    n = t * b * p
+    dev = pybsgs.Device(0)
+    A = ecpy.addpubg(w)
+    dev.generate_g2(A[0], A[1], t, b, p)
+    img = dev.download_g2(64 * n)
+    assert len(img) == 64 * n
+    rnd = random.Random(24)
+    for i in [0, 1, p - 1, p, n - 1, n - p, n // 2] + [rnd.randrange(n) for _ in range(13)]:
+        assert O.g2_unpack(img, t, b, p, i) == ecpy.mul((i + 1) * (N - 2 * w) % N), i
+    dev.close()
