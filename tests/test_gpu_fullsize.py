@@ -204,3 +204,39 @@ def test_gpu_generated_giants_at_full_geometry():
     for i in [0, 1, p - 1, p, n - 1, n - p, n // 2] + [rnd.randrange(n) for _ in range(13)]:
         assert O.g2_unpack(img, t, b, p, i) == ecpy.mul((i + 1) * (N - 2 * w) % N), i
     dev.close()
+
+
+def test_hit_lists_of_two_independent_kernels_agree_under_load():
+    """144 tiles (4.8e9 probes) at the metric's size through the default kernel (LDS-DMA staged probes behind counted
+    vmcnt waits, pair-batched chain) and through the plain per-giant kernel with the exact CSR probe: the complete hit
+    lists -- about 4 genuine 32-bit hash collisions plus the planted ones -- must be identical.  A probe compared before
+    its line has landed, or a chain entry read before it was written, would show up as a difference."""
+    import pybsgs
+    from pybsgs import ecpy
+    wexp, htsz = 30, 28
+    t, b, p, w = 256, 256, 256, 1 << wexp
+    maxnonce = t * b * p
+    dev = pybsgs.Device(0)
+    img = torch.empty((1 << htsz) + 1 + w, dtype=torch.int32, device="cuda:0")
+    dev.build_baby_tables_device(w, htsz, img.data_ptr())
+    A = ecpy.addpubg(w)
+    dev.generate_g2(A[0], A[1], t, b, p)
+    gstep, stride_pt = ecpy.tile_stride(t, b, p, w)
+    cur = ecpy.mul(0xDEADBEEFCAFE1234567)
+    centres = []
+    for k in range(144):
+        centres.append(cur)
+        cur = ecpy.add(cur, stride_pt)
+    centres[5] = ecpy.mul((777 * 2 * w + 31337) % N)            # planted: code 1 at giant 776
+    centres[143] = ecpy.mul((N - (maxnonce * 2 * w) + 99) % N)  # planted: code 2 at the last giant
+    res = {}
+    for layout in (pybsgs.TABLE_LINES64, pybsgs.TABLE_CSR):
+        dev.upload_htgpu_device(img.data_ptr(), 1 << htsz, w, layout)
+        hits, n, _ = dev.run(centres, 65536)
+        assert n == len(hits)
+        res[layout] = hits
+    assert res[pybsgs.TABLE_LINES64] == res[pybsgs.TABLE_CSR]
+    got = res[pybsgs.TABLE_LINES64]
+    assert (5, 1, 776) in got and (143, 2, maxnonce - 1) in got
+    assert 2 <= len(got) <= 30
+    dev.close()
