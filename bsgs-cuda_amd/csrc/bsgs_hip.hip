@@ -78,6 +78,8 @@ static void free_g2(bsgs_dev *d)
     if (d->g2) (void)hipFree(d->g2);
     if (d->chain) (void)hipFree(d->chain);
     if (d->schain) (void)hipFree(d->schain);
+    if (d->pool) (void)hipFree(d->pool);
+    d->pool = nullptr;
     d->g2 = nullptr; d->chain = nullptr; d->chain_bytes = 0; d->schain = nullptr; d->schain_blocks = 0;
 }
 
@@ -170,7 +172,7 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
 // one product per two giants); `full` = the caller is a generator kernel that needs the per-giant chain of one tile
 static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
 {
-    const bool halfchain = !full && d->variant == 10 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);   // = the dispatch of giant_pair2_kernel
+    const bool halfchain = !full && (d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);   // = the dispatch of giant_pair2_kernel
     const uint64_t per_stream = d->maxnonce * (halfchain ? 16 : 32) * tiles;
     const uint64_t bytes = per_stream * (d->nstreams == 2 ? 2 : 1);                 // one scratch per stream
     if (d->chain && d->chain_bytes >= bytes) { d->chain_stride = per_stream / 16; return BSGS_OK; }
@@ -412,6 +414,7 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;
+    A.centres_dev = nullptr; A.pool = nullptr; A.pool_cap = 0; A.pool_stride = 0;
     memset(A.centre, 0, sizeof A.centre);
     for (uint32_t k = 0; k < ntiles; k++) {
         le_to_fe(A.centre[2 * k], centres + (size_t)k * 64);
@@ -425,7 +428,7 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
         HIPCHK(hipGetLastError());
         return BSGS_OK;
     }
-    if (d->variant == 10 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+    if ((d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         const bool l128 = d->layout == BSGS_TABLE_LINES128;
         const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
         const bool dbg = d->debug_flags != 0 || d->phase_probe;
@@ -434,7 +437,7 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
         HIPCHK(hipGetLastError());
         return BSGS_OK;
     }
-    if ((d->variant == 9 || d->variant == 10) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+    if ((d->variant >= 9 && d->variant <= 11) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         const bool l128 = d->layout == BSGS_TABLE_LINES128;
         const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
         const bool dbg = d->debug_flags != 0 || d->phase_probe;
@@ -512,6 +515,59 @@ static int launch_stream(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, u
     return BSGS_OK;
 }
 
+// ---- pooled launch (BSGS_KERNEL_VARIANT=11): ONE launch for the whole queue.  The chain scratch belongs to resident blocks
+// (slots handed out by a per-XCD ring inside the kernel), the centres are read from device memory.
+static int ensure_pool(bsgs_dev *d)
+{
+    const uint32_t cap = 256;                                  // >= 2 x the 128 blocks of 256 threads one XCD holds at 4 waves per SIMD
+    if (!d->nxcc) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, d->id) != hipSuccess || n < 1) n = 8;
+        d->nxcc = (uint32_t)std::min(n, 16);
+    }
+    const uint64_t bytes = (uint64_t)d->nxcc * cap * d->pi * d->block_size * 16;       // [xcc][slot][pair][2][block] of 16 bytes, pi/2 pairs
+    if (!d->pool) {
+        const uint32_t stride = 16 + cap;
+        std::vector<uint32_t> h((size_t)d->nxcc * stride, 0);
+        for (uint32_t x = 0; x < d->nxcc; x++) for (uint32_t s = 0; s < cap; s++) h[(size_t)x * stride + 16 + s] = s;
+        HIPCHK(hipMalloc(&d->pool, h.size() * 4));
+        HIPCHK(hipMemcpy(d->pool, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        d->pool_cap = cap; d->pool_stride = stride;
+    }
+    if (d->chain && d->chain_bytes >= bytes) return BSGS_OK;
+    if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
+    if (hipMalloc(&d->chain, bytes) != hipSuccess) { d->chain = nullptr; return fail(BSGS_ERR_NOMEM, "pooled chain scratch: %.1f GiB", bytes / 1073741824.0); }
+    d->chain_bytes = bytes;
+    return BSGS_OK;
+}
+
+static int launch_pooled(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq)
+{
+    int rc = ensure_pool(d);
+    if (rc) return rc;
+    void *pin = nullptr, *dc = nullptr;
+    HIPCHK(hipHostMalloc(&pin, (size_t)ntiles * 64, hipHostMallocDefault));
+    d->pending_pinned.push_back(pin);
+    memcpy(pin, centres, (size_t)ntiles * 64);
+    HIPCHK(hipMalloc(&dc, (size_t)ntiles * 64));
+    d->pending_dev.push_back(dc);
+    HIPCHK(hipMemcpyAsync(dc, pin, (size_t)ntiles * 64, hipMemcpyHostToDevice, d->stream));
+    TileArgs A;
+    memset(&A, 0, sizeof A);
+    A.g2 = d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
+    A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
+    A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
+    A.centres_dev = (const fe *)dc; A.pool = d->pool; A.pool_cap = d->pool_cap; A.pool_stride = d->pool_stride;
+    const unsigned bs = d->block_size;
+    const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
+    const bool l128 = d->layout == BSGS_TABLE_LINES128;
+    const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096) + 16;
+    if (l128) hipLaunchKernelGGL((giant_pair2_kernel<3, false, true>), grid, block, lds, d->stream, A);
+    else      hipLaunchKernelGGL((giant_pair2_kernel<2, false, true>), grid, block, lds, d->stream, A);
+    HIPCHK(hipGetLastError());
+    return BSGS_OK;
+}
+
 extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
 {
     if (!d || !centres) return fail(BSGS_ERR_ARG, "null");
@@ -524,6 +580,21 @@ extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles
         int rcs = launch_stream(d, centres, ntiles, d->queued);
         if (rcs) return rcs;
         d->launches++;
+        d->queued += ntiles;
+        return BSGS_OK;
+    }
+    const bool pooled = d->variant == 11 && (d->pi & 1u) == 0 && !d->debug_flags && !d->phase_probe && d->nstreams == 1 && !d->tiles_per_launch &&
+                        (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
+    if (pooled) {
+        if (!ntiles) return BSGS_OK;
+        if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0)); d->timing_open = true; }
+        static const uint32_t cap = getenv("BSGS_POOL_TILES") ? (uint32_t)std::max(1, atoi(getenv("BSGS_POOL_TILES"))) : 4096u;
+        for (uint32_t k = 0; k < ntiles; k += cap) {                      // one launch per `cap` tiles at most
+            const uint32_t n = std::min<uint32_t>(cap, ntiles - k);
+            int rcp = launch_pooled(d, centres + (size_t)k * 64, n, d->queued + k);
+            if (rcp) return rcp;
+            d->launches++;
+        }
         d->queued += ntiles;
         return BSGS_OK;
     }

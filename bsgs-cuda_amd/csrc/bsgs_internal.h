@@ -28,6 +28,8 @@ struct bsgs_dev {
     uint64_t T = 0, maxnonce = 0;
     uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
     uint64_t chain_bytes = 0, chain_stride = 0;   // size of the chain scratch; u32x4 elements per stream
+    u32 *pool = nullptr;                   // pooled launches: per-XCD rings of free chain slots
+    uint32_t pool_cap = 0, pool_stride = 0, nxcc = 0;
     u32x4 *schain = nullptr;               // streamed kernel: one scratch slot per resident block
     uint64_t schain_blocks = 0;
     std::vector<void *> pending_dev, pending_pinned;   // per-enqueue centre buffers, released by bsgs_collect
@@ -50,7 +52,8 @@ struct bsgs_dev {
     uint64_t launches = 0;
     int variant = 10;           // BSGS_KERNEL_VARIANT (all bit-identical): per-tile kernels 0 synchronous probes, 1 pipelined probes,
                                 // 2 early / 7 late prefetch, 8 = 7 + LDS-staged probe, 9 = both probes LDS-staged, 6 pair-batched chain,
-                                // 10 = 9 + pair-batched chain (default; falls back to 9 for an odd chain length); streamed ping-pong
+                                // 10 = 9 + pair-batched chain (default; falls back to 9 for an odd chain length), 11 = 10 as ONE launch
+                                // per queue with pooled chain scratch (slower sustained: DESIGN.md 8); streamed ping-pong
                                 // kernels 3, 4 (LDS probes), 5 (all loads LDS-staged, counted vmcnt)
     bool timing_open = false;
 };
