@@ -44,10 +44,14 @@ td.destroy_process_group()
 def test_two_ranks_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text("ROOT = %r\nOUT = %r\n" % (ROOT, str(tmp_path)) + WORKER)
+    import socket
+    with socket.socket() as sk:                      # a port nobody holds (a fixed one may sit in TIME_WAIT after a previous run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", str(script)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)      # three cold `import torch` can take minutes
     assert res.returncode == 0, res.stderr[-2000:]
     r = [json.load(open(tmp_path / ("r%d.json" % k))) for k in range(2)]
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "small_w1024_ht8_t2_b2_p4.json")))
