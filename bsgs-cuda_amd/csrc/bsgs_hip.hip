@@ -430,7 +430,7 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
     }
     if ((d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         const bool l128 = d->layout == BSGS_TABLE_LINES128;
-        const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
+        const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048);           // probe slots + S stash per wave: 4 blocks fill the 160 KiB of a CU exactly
         const bool dbg = d->debug_flags != 0 || d->phase_probe;
         if (l128) { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<3, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<3, false>), grid, block, lds, st, A); }
         else      { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<2, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<2, false>), grid, block, lds, st, A); }
@@ -561,7 +561,7 @@ static int launch_pooled(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, u
     const unsigned bs = d->block_size;
     const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
     const bool l128 = d->layout == BSGS_TABLE_LINES128;
-    const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096) + 16;
+    const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048) + 16;
     if (l128) hipLaunchKernelGGL((giant_pair2_kernel<3, false, true>), grid, block, lds, d->stream, A);
     else      hipLaunchKernelGGL((giant_pair2_kernel<2, false, true>), grid, block, lds, d->stream, A);
     HIPCHK(hipGetLastError());
