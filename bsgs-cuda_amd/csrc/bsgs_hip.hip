@@ -346,12 +346,15 @@ static int finish_table(bsgs_dev *d, uint64_t ht_items, uint64_t w, uint32_t lay
     d->ht_items = ht_items; d->w = w;
     if (layout == BSGS_TABLE_AUTO) {
         // mean bucket load decides the line size; fall back to CSR when the lines do not fit in free memory
+        // up to 5 entries per bucket: 64-byte lines, the few over-full buckets through the resident CSR image; up to 9: still
+        // 64-byte lines, but ~1 % of the probes then need the fallback, which has to be the hash set (1.5 reads, not a CSR
+        // search): the CSR image is dropped; up to 20: 128-byte lines + hash set; beyond that the exact CSR probe
         const double load = (double)w / (double)ht_items;
-        layout = load <= 5.0 ? BSGS_TABLE_LINES64 : BSGS_TABLE_LINES128;
+        layout = load <= 5.0 ? BSGS_TABLE_LINES64 : load <= 9.0 ? BSGS_TABLE_LINES64_LIST : BSGS_TABLE_LINES128_LIST;
         size_t fr = 0, tot = 0;
         HIPCHK(hipMemGetInfo(&fr, &tot));
-        const uint64_t need = ht_items * (layout == BSGS_TABLE_LINES64 ? 64ull : 128ull);
-        if (load > 14.0 || need + (1ull << 30) > fr) layout = BSGS_TABLE_CSR;
+        const uint64_t need = ht_items * (layout == BSGS_TABLE_LINES128_LIST ? 128ull : 64ull);
+        if (load > 20.0 || need + (1ull << 30) > fr) layout = BSGS_TABLE_CSR;
     }
     if (layout == BSGS_TABLE_CSR) { d->layout = BSGS_TABLE_CSR; d->lines_bytes = 0; d->overflow = 0; return BSGS_OK; }
     if (layout == BSGS_TABLE_LINES64_LIST) return build_lines(d, BSGS_TABLE_LINES64, true);
