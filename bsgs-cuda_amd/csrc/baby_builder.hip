@@ -358,9 +358,9 @@ extern "C" int bsgs_build_baby_tables(bsgs_dev *d, uint64_t w, uint32_t htsz, vo
     if (install_layout != BSGS_NO_INSTALL) {
         // hand the device image to the engine (it becomes the owner)
         rc = bsgs_upload_htgpu_device(d, img_gpu.p, ht_items, w, install_layout);
-        if (rc) return rc;
-        d->csr_owned = true;
-        img_gpu.p = nullptr;
+        if (rc) { bsgs_free_table(d); return rc; }        // the borrowed image dies with img_gpu: leave no pointer to it behind
+        // layouts that keep the CSR image as their fallback now own it; the *_LIST layouts dropped it (img_gpu frees it)
+        if (d->csr == img_gpu.as<u32>()) { d->csr_owned = true; img_gpu.p = nullptr; }
     }
     return BSGS_OK;
 }

@@ -80,6 +80,8 @@ static void free_g2(bsgs_dev *d)
     if (d->schain) (void)hipFree(d->schain);
     if (d->pool) (void)hipFree(d->pool);
     d->pool = nullptr;
+    if (d->quirk_list) (void)hipFree(d->quirk_list);
+    d->quirk_list = nullptr; d->quirk_host.clear(); d->quirk_ready = false;
     d->g2 = nullptr; d->chain = nullptr; d->chain_bytes = 0; d->schain = nullptr; d->schain_blocks = 0;
 }
 
@@ -92,6 +94,10 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     free_table(d); free_g2(d);
     if (d->hitbuf) (void)hipFree(d->hitbuf);
     if (d->hit_host) (void)hipHostFree(d->hit_host);
+    if (d->cen_dev) (void)hipFree(d->cen_dev);
+    if (d->cen_pin) (void)hipHostFree(d->cen_pin);
+    if (d->walk_table) (void)hipFree(d->walk_table);
+    if (d->digest) (void)hipFree(d->digest);
     (void)hipStreamSynchronize(d->stream2);
     (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->evj);
     (void)hipStreamDestroy(d->stream); (void)hipStreamDestroy(d->stream2);
@@ -136,8 +142,31 @@ extern "C" int bsgs_steps_per_tile(bsgs_dev *d, uint64_t *steps)
 
 extern "C" int bsgs_set_tiles_per_launch(bsgs_dev *d, uint32_t n)
 {
-    if (!d || n > BSGS_TILES_PER_LAUNCH) return fail(BSGS_ERR_ARG, "tiles per launch must be 0 (auto) or 1..%d", BSGS_TILES_PER_LAUNCH);
+    if (!d || n > BSGS_TILES_PER_LAUNCH_MAX) return fail(BSGS_ERR_ARG, "tiles per launch must be 0 (auto) or 1..%d", BSGS_TILES_PER_LAUNCH_MAX);
     d->tiles_per_launch = n;
+    return BSGS_OK;
+}
+static uint32_t auto_tiles_per_launch(const bsgs_dev *d);
+extern "C" int bsgs_tiles_per_launch(bsgs_dev *d, uint32_t *n)
+{
+    if (!d || !n) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2) return fail(BSGS_ERR_STATE, "no giants on device: the launch shape follows the geometry");
+    *n = auto_tiles_per_launch(d);
+    return BSGS_OK;
+}
+extern "C" int bsgs_engine_geometry(bsgs_dev *d, uint32_t *threads, uint32_t *giants_per_thread)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2) return fail(BSGS_ERR_STATE, "no giants on device");
+    if (threads) *threads = d->Ti;
+    if (giants_per_thread) *giants_per_thread = d->pi;
+    return BSGS_OK;
+}
+extern "C" int bsgs_set_flags(bsgs_dev *d, uint32_t flags)
+{
+    if (!d || (flags & ~BSGS_FLAG_REFERENCE_QUIRKS)) return fail(BSGS_ERR_ARG, "unknown flag bits %#x", flags);
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    d->flags = flags;
     return BSGS_OK;
 }
 extern "C" int bsgs_launch_count(bsgs_dev *d, uint64_t *launches)
@@ -409,7 +438,23 @@ extern "C" int bsgs_table_info(bsgs_dev *d, uint32_t *layout, uint64_t *device_b
 // ---- tiles ------------------------------------------------------------------------------------------------
 static void le_to_fe(fe &f, const uint8_t *le) { memcpy(f.v, le, 32); }
 
-static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq, int which)
+// grow-only device + pinned buffers for the centres of the queued tiles
+static int ensure_centres(bsgs_dev *d, uint64_t tiles)
+{
+    if (tiles <= d->cen_cap) return BSGS_OK;
+    uint64_t cap = d->cen_cap ? d->cen_cap : 4096;
+    while (cap < tiles) cap *= 2;
+    fe *nd = nullptr; uint8_t *np = nullptr;
+    HIPCHK(hipMalloc(&nd, cap * 64));
+    if (hipHostMalloc(&np, cap * 64, hipHostMallocDefault) != hipSuccess) { (void)hipFree(nd); return fail(BSGS_ERR_NOMEM, "pinned centre staging"); }
+    if (d->cen_dev) d->pending_dev.push_back(d->cen_dev);       // launches in flight still read the old buffer
+    if (d->cen_pin) d->pending_pinned.push_back(d->cen_pin);
+    d->cen_dev = nd; d->cen_pin = np; d->cen_cap = cap;
+    return BSGS_OK;
+}
+
+static int quirk_prepare(bsgs_dev *d);
+static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uint32_t seq, int which)
 {
     TileArgs A;
     hipStream_t st = which ? d->stream2 : d->stream;
@@ -417,13 +462,16 @@ static int launch_tiles(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, ui
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;
-    A.centres_dev = nullptr; A.pool = nullptr; A.pool_cap = 0; A.pool_stride = 0;
-    memset(A.centre, 0, sizeof A.centre);
-    for (uint32_t k = 0; k < ntiles; k++) {
-        le_to_fe(A.centre[2 * k], centres + (size_t)k * 64);
-        le_to_fe(A.centre[2 * k + 1], centres + (size_t)k * 64 + 32);
-    }
+    A.centres_dev = centres_dev; A.pool = nullptr; A.pool_cap = 0; A.pool_stride = 0;
+    A.digest = d->digest ? d->digest + (uint64_t)seq * d->Ti * 2 : nullptr;
     const unsigned bs = d->block_size;
+    if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) {
+        // the reference's own P - G arithmetic for the listed giants; bsgs_collect drops the hot loop's records for them
+        const uint32_t nfix = (uint32_t)d->quirk_host.size() * ntiles;
+        hipLaunchKernelGGL(quirk_fix_kernel, dim3((nfix + 63) / 64), dim3(64), 0, st, A, d->layout == BSGS_TABLE_LINES128 ? 3 : 2,
+                           (const u32 *)d->quirk_list, (u32)d->quirk_host.size());
+        HIPCHK(hipGetLastError());
+    }
     const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
     if (d->variant == 6 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         if (d->layout == BSGS_TABLE_LINES64) hipLaunchKernelGGL(giant_pair_kernel<2>, grid, block, 0, st, A);
@@ -571,14 +619,42 @@ static int launch_pooled(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, u
     return BSGS_OK;
 }
 
-extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
+// giants whose Gy trips the reference's NEGMODP (quirk mode): listed once per G2 upload
+static int quirk_prepare(bsgs_dev *d)
 {
-    if (!d || !centres) return fail(BSGS_ERR_ARG, "null");
-    if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
-    HIPCHK(hipSetDevice(d->id));
-    const bool streamed = (d->variant >= 3 && d->variant <= 5) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
+    if (d->quirk_ready) return BSGS_OK;
+    const uint32_t cap = 1u << 16;                           // 2.3e-7 of < 2^32 giants: about 1000 at most
+    u32 *cnt = nullptr;
+    if (!d->quirk_list) HIPCHK(hipMalloc(&d->quirk_list, (size_t)cap * 4));
+    HIPCHK(hipMalloc(&cnt, 4));
+    HIPCHK(hipMemsetAsync(cnt, 0, 4, d->stream));
+    const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
+    hipLaunchKernelGGL(quirk_scan_kernel, dim3(blocks), dim3(256), 0, d->stream, d->g2, d->Ti, d->pi, d->quirk_list, cap, cnt);
+    uint32_t n = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&n, cnt, 4, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void)hipFree(cnt);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "quirk scan: %s", hipGetErrorString(e));
+    if (n > cap) return fail(BSGS_ERR_NOMEM, "quirk list: %u giants, room for %u", n, cap);
+    d->quirk_host.resize(n);
+    if (n) HIPCHK(hipMemcpy(d->quirk_host.data(), d->quirk_list, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::sort(d->quirk_host.begin(), d->quirk_host.end());
+    if (n) HIPCHK(hipMemcpy(d->quirk_list, d->quirk_host.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    d->quirk_ready = true;
+    return BSGS_OK;
+}
+
+static bool lines_layout(const bsgs_dev *d) { return d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128; }
+
+// queue `ntiles` tiles whose centres are already in d->cen_dev[2*queued ...] (or, for the streamed / pooled variants that
+// keep their own buffers, in the host array `centres`)
+static int enqueue_common(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
+{
+    const bool quirks = (d->flags & BSGS_FLAG_REFERENCE_QUIRKS) != 0;
+    if (quirks) { int rq = quirk_prepare(d); if (rq) return rq; }
+    const bool streamed = centres && !quirks && !d->digest && (d->variant >= 3 && d->variant <= 5) && lines_layout(d);
     if (streamed) {
-        if (!ntiles) return BSGS_OK;
         if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0)); d->timing_open = true; }
         int rcs = launch_stream(d, centres, ntiles, d->queued);
         if (rcs) return rcs;
@@ -586,10 +662,9 @@ extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles
         d->queued += ntiles;
         return BSGS_OK;
     }
-    const bool pooled = d->variant == 11 && (d->pi & 1u) == 0 && !d->debug_flags && !d->phase_probe && d->nstreams == 1 && !d->tiles_per_launch &&
-                        (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
+    const bool pooled = centres && !quirks && !d->digest && d->variant == 11 && (d->pi & 1u) == 0 && !d->debug_flags && !d->phase_probe && d->nstreams == 1 &&
+                        !d->tiles_per_launch && lines_layout(d);
     if (pooled) {
-        if (!ntiles) return BSGS_OK;
         if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0)); d->timing_open = true; }
         static const uint32_t cap = getenv("BSGS_POOL_TILES") ? (uint32_t)std::max(1, atoi(getenv("BSGS_POOL_TILES"))) : 4096u;
         for (uint32_t k = 0; k < ntiles; k += cap) {                      // one launch per `cap` tiles at most
@@ -609,14 +684,102 @@ extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles
         HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0));     // stream2 starts after the timing origin (and after uploads)
         d->timing_open = true;
     }
+    if (d->nstreams == 2) {                                    // the centres were written on the main stream
+        HIPCHK(hipEventRecord(d->evj, d->stream));
+        HIPCHK(hipStreamWaitEvent(d->stream2, d->evj, 0));
+    }
     for (uint32_t k = 0; k < ntiles; k += tpl) {
         const uint32_t n = std::min<uint32_t>(tpl, ntiles - k);
         const int which = d->nstreams == 2 ? (int)(d->launches & 1) : 0;
-        int rc = launch_tiles(d, centres + (size_t)k * 64, n, d->queued + k, which);
+        int rc = launch_tiles(d, d->cen_dev + 2 * (uint64_t)(d->queued + k), n, d->queued + k, which);
         if (rc) return rc;
         d->launches++;
     }
     d->queued += ntiles;
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
+{
+    if (!d || !centres) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
+    if (!ntiles) return BSGS_OK;
+    HIPCHK(hipSetDevice(d->id));
+    int rc = ensure_centres(d, (uint64_t)d->queued + ntiles);
+    if (rc) return rc;
+    uint8_t *pin = d->cen_pin + (size_t)d->queued * 64;       // a fresh region per enqueue: nothing queued is overwritten
+    memcpy(pin, centres, (size_t)ntiles * 64);
+    HIPCHK(hipMemcpyAsync(d->cen_dev + 2 * (uint64_t)d->queued, pin, (size_t)ntiles * 64, hipMemcpyHostToDevice, d->stream));
+    return enqueue_common(d, centres, ntiles);
+}
+
+// ---- device-side tile walk: replaces GetJob's host point addition + the per-launch upload (1_9_7File.pb:2077-2092, 2435-2445) ----
+extern "C" int bsgs_set_walk(bsgs_dev *d, const uint8_t p0_xy_le[64], const uint8_t stride_xy_le[64])
+{
+    if (!d || !p0_xy_le || !stride_xy_le) return fail(BSGS_ERR_ARG, "null");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    HIPCHK(hipSetDevice(d->id));
+    hs::Affine D = hs::affine_from_le(stride_xy_le, stride_xy_le + 32), P0 = hs::affine_from_le(p0_xy_le, p0_xy_le + 32);
+    if (!hs::on_curve(D) || !hs::on_curve(P0)) return fail(BSGS_ERR_ARG, "walk: P0 / stride is not a curve point");
+    std::vector<uint8_t> tab(64 * 64);
+    hs::Affine cur = D;
+    for (int j = 0; j < 64; j++) {
+        if (cur.inf) return fail(BSGS_ERR_ARG, "walk: 2^%d * stride is the point at infinity", j);
+        hs::affine_to_le(cur, &tab[(size_t)j * 64], &tab[(size_t)j * 64 + 32]);
+        cur = hs::point_add(cur, cur);
+    }
+    if (!d->walk_table) HIPCHK(hipMalloc(&d->walk_table, tab.size()));
+    HIPCHK(hipMemcpy(d->walk_table, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    le_to_fe(d->walk_p0x, p0_xy_le); le_to_fe(d->walk_p0y, p0_xy_le + 32);
+    d->walk_set = true;
+    return BSGS_OK;
+}
+
+extern "C" int bsgs_enqueue_walk(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (!d->walk_set) return fail(BSGS_ERR_STATE, "bsgs_set_walk first");
+    if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
+    if (!ntiles) return BSGS_OK;
+    if (first_tile + ntiles < first_tile) return fail(BSGS_ERR_ARG, "tile index overflows 64 bits");
+    HIPCHK(hipSetDevice(d->id));
+    int rc = ensure_centres(d, (uint64_t)d->queued + ntiles);
+    if (rc) return rc;
+    hipLaunchKernelGGL(walk_centres_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, d->stream, d->walk_p0x, d->walk_p0y,
+                       (const fe *)d->walk_table, (u64)first_tile, (u32)ntiles, d->cen_dev + 2 * (uint64_t)d->queued, d->hitbuf + BSGS_HIT_WALK_STATUS);
+    HIPCHK(hipGetLastError());
+    return enqueue_common(d, nullptr, ntiles);
+}
+
+extern "C" int bsgs_run_walk(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, bsgs_hit_ex *hits, uint32_t max_hits,
+                             uint32_t *nhits, float *kernel_ms)
+{
+    int rc = bsgs_enqueue_walk(d, first_tile, ntiles);
+    if (rc) return rc;
+    return bsgs_collect(d, hits, max_hits, nhits, kernel_ms);
+}
+
+// the centres bsgs_enqueue_walk would use, for callers that need a tile's centre on the host (resolving a hit) and for tests
+extern "C" int bsgs_walk_centres(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, uint8_t *centres_out)
+{
+    if (!d || !centres_out) return fail(BSGS_ERR_ARG, "null");
+    if (!d->walk_set) return fail(BSGS_ERR_STATE, "bsgs_set_walk first");
+    if (!ntiles) return BSGS_OK;
+    HIPCHK(hipSetDevice(d->id));
+    fe *tmp = nullptr; u32 *st = nullptr;
+    HIPCHK(hipMalloc(&tmp, (size_t)ntiles * 64));
+    if (hipMalloc(&st, 4) != hipSuccess) { (void)hipFree(tmp); return fail(BSGS_ERR_NOMEM, "status word"); }
+    hipError_t e = hipMemsetAsync(st, 0, 4, d->stream);
+    hipLaunchKernelGGL(walk_centres_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, d->stream, d->walk_p0x, d->walk_p0y,
+                       (const fe *)d->walk_table, (u64)first_tile, (u32)ntiles, tmp, st);
+    if (e == hipSuccess) e = hipGetLastError();
+    uint32_t bad = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, st, 4, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e == hipSuccess) e = hipMemcpy(centres_out, tmp, (size_t)ntiles * 64, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp); (void)hipFree(st);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "walk_centres: %s", hipGetErrorString(e));
+    if (bad) return fail(BSGS_ERR_DEGENERATE, "%u tile centre(s) are the point at infinity", bad);
     return BSGS_OK;
 }
 
@@ -633,6 +796,8 @@ extern "C" int bsgs_collect(bsgs_dev *d, bsgs_hit_ex *hits, uint32_t max_hits, u
     HIPCHK(hipMemcpyAsync(d->hit_host, d->hitbuf, 64, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     uint32_t n = d->hit_host[0];
+    const uint32_t raw_n = n;
+    const uint32_t walk_bad = d->hit_host[BSGS_HIT_WALK_STATUS];
     if (kernel_ms) {
         *kernel_ms = 0.f;
         if (d->timing_open) {
@@ -650,19 +815,36 @@ extern "C" int bsgs_collect(bsgs_dev *d, bsgs_hit_ex *hits, uint32_t max_hits, u
         HIPCHK(hipMemcpyAsync(d->hit_host + BSGS_HIT_HEADER_WORDS, d->hitbuf + BSGS_HIT_HEADER_WORDS, (size_t)stored * 16,
                               hipMemcpyDeviceToHost, d->stream));
     }
-    if (n) HIPCHK(hipMemsetAsync(d->hitbuf, 0, 64, d->stream));       // the host zeroes the counter after draining (1_9_7File.pb:2502-2503)
+    if (n || walk_bad) HIPCHK(hipMemsetAsync(d->hitbuf, 0, 64, d->stream));       // the host zeroes the counter after draining (1_9_7File.pb:2502-2503)
     HIPCHK(hipStreamSynchronize(d->stream));
-    if (nhits) *nhits = n;
+    if (walk_bad) {
+        if (nhits) *nhits = 0;
+        return fail(BSGS_ERR_DEGENERATE, "%u tile centre(s) of the device walk are the point at infinity: dispense this batch with host centres", walk_bad);
+    }
     const bsgs_hit_ex *rec = (const bsgs_hit_ex *)(d->hit_host + BSGS_HIT_HEADER_WORDS);
     std::vector<bsgs_hit_ex> v(rec, rec + stored);
+    if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) {
+        // reference-quirk mode: for the listed giants the P - G record comes from quirk_fix_kernel (word 3 = 1), not from the hot loop
+        size_t k = 0;
+        uint32_t dropped = 0;
+        for (size_t i = 0; i < v.size(); i++) {
+            const bool listed = v[i].code == 2 && std::binary_search(d->quirk_host.begin(), d->quirk_host.end(), v[i].idx);
+            if (listed && v[i].reserved == 0) { dropped++; continue; }
+            v[k] = v[i]; v[k].reserved = 0; k++;
+        }
+        v.resize(k);
+        n -= std::min(n, dropped);
+    }
+    if (nhits) *nhits = n;
+    const uint32_t kept = (uint32_t)v.size();
     std::sort(v.begin(), v.end(), [](const bsgs_hit_ex &x, const bsgs_hit_ex &y) {
         if (x.tile != y.tile) return x.tile < y.tile;
         if (x.idx != y.idx) return x.idx < y.idx;
         return x.code < y.code;
     });
-    const uint32_t ncopy = std::min<uint32_t>(stored, max_hits);
+    const uint32_t ncopy = std::min<uint32_t>(kept, max_hits);
     if (hits && ncopy) memcpy(hits, v.data(), (size_t)ncopy * sizeof(bsgs_hit_ex));
-    if (n > max_hits || n > d->max_hits) return fail(BSGS_ERR_OVERFLOW, "%u hits, room for %u", n, std::min(max_hits, d->max_hits));
+    if (n > max_hits || raw_n > d->max_hits) return fail(BSGS_ERR_OVERFLOW, "%u hits, room for %u", raw_n, std::min(max_hits, d->max_hits));
     return BSGS_OK;
 }
 
@@ -688,6 +870,86 @@ extern "C" int bsgs_step(bsgs_dev *d, const uint8_t px_le[32], const uint8_t py_
     const uint32_t m = std::min(n, max_hits);
     for (uint32_t i = 0; i < m && hits; i++) { hits[i].code = ex[i].code; hits[i].idx = ex[i].idx; }
     return rc;
+}
+
+// ---- probe digest (parity instrumentation): per engine thread, XOR and wrapping sum of every 64-bit key it probed -------
+extern "C" int bsgs_run_digest(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint64_t *digest_out, bsgs_hit_ex *hits,
+                               uint32_t max_hits, uint32_t *nhits)
+{
+    if (!d || !centres || !digest_out) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    if ((d->pi & 1u) || !lines_layout(d)) return fail(BSGS_ERR_STATE, "the digest is an instrument of the default (pair-batched, bucket-line) kernel");
+    HIPCHK(hipSetDevice(d->id));
+    const uint64_t bytes = (uint64_t)ntiles * d->Ti * 16;
+    HIPCHK(hipMalloc(&d->digest, bytes));
+    hipError_t e = hipMemsetAsync(d->digest, 0, bytes, d->stream);
+    const unsigned saved_flags = d->debug_flags;
+    const int saved_variant = d->variant;
+    d->debug_flags = 8u; d->variant = 10; d->phase_probe = true;
+    int rc = e == hipSuccess ? bsgs_run(d, centres, ntiles, hits, max_hits, nhits, nullptr) : fail(BSGS_ERR_HIP, "memset: %s", hipGetErrorString(e));
+    d->debug_flags = saved_flags; d->variant = saved_variant; d->phase_probe = false;
+    if (rc == BSGS_OK || rc == BSGS_ERR_OVERFLOW) {
+        e = hipMemcpy(digest_out, d->digest, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(BSGS_ERR_HIP, "digest read-back: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d->digest);
+    d->digest = nullptr;
+    return rc;
+}
+
+// ---- replicas for several GPUs of one process: the reference uploads G2 and htGPU to every GPU over PCIe (1_9_7File.pb:2337,
+// 2350, 4769-4843).  Here devs[0] holds the giants and the table (file-backed or GPU-built) and every other device gets its
+// replica by a direct device-to-device copy, all destinations at once, each on its own stream: on the fully connected xGMI mesh
+// of an MI355X node every destination has its own link to the source, so N-1 concurrent peer copies ARE the one-to-all schedule
+// (multi-process hosts broadcast with RCCL instead: bench.py / pybsgs.dist).
+extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
+{
+    if (!devs || n < 1 || !devs[0]) return fail(BSGS_ERR_ARG, "null");
+    bsgs_dev *s = devs[0];
+    if (!s->g2 || !s->layout) return fail(BSGS_ERR_STATE, "devs[0] must hold the giants and the table");
+    for (int i = 1; i < n; i++) {
+        bsgs_dev *d = devs[i];
+        if (!d) return fail(BSGS_ERR_ARG, "null device %d", i);
+        if (d == s) continue;
+        HIPCHK(hipSetDevice(d->id));
+        if (d->id != s->id) {
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, d->id, s->id) == hipSuccess && can) {
+                hipError_t pe = hipDeviceEnablePeerAccess(s->id, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(BSGS_ERR_HIP, "peer access %d -> %d: %s", d->id, s->id, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+        }
+        int rc = set_geometry(d, s->t, s->b, s->p);
+        if (rc) return rc;
+        if (d->Ti != s->Ti || d->pi != s->pi) return fail(BSGS_ERR_STATE, "device %d chose another batching", i);
+        free_table(d);
+        HIPCHK(hipMemcpyPeerAsync(d->g2, d->id, s->g2, s->id, s->maxnonce * 64, d->stream));
+        d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->layout = s->layout; d->lines_bytes = s->lines_bytes;
+        if (s->csr) {
+            const uint64_t bytes = 4 * (s->ht_items + 1) + 4 * s->w;
+            HIPCHK(hipMalloc(&d->csr, bytes));
+            d->csr_owned = true;
+            HIPCHK(hipMemcpyPeerAsync(d->csr, d->id, s->csr, s->id, bytes, d->stream));
+        }
+        if (s->lines) {
+            HIPCHK(hipMalloc(&d->lines, s->lines_bytes));
+            d->lines_owned = true;
+            HIPCHK(hipMemcpyPeerAsync(d->lines, d->id, s->lines, s->id, s->lines_bytes, d->stream));
+        }
+        if (s->ovf) {
+            HIPCHK(hipMalloc(&d->ovf, s->ovf_n * 8));
+            d->ovf_n = s->ovf_n;
+            HIPCHK(hipMemcpyPeerAsync(d->ovf, d->id, s->ovf, s->id, s->ovf_n * 8, d->stream));
+        }
+    }
+    for (int i = 1; i < n; i++) {
+        if (devs[i] == s) continue;
+        HIPCHK(hipSetDevice(devs[i]->id));
+        HIPCHK(hipStreamSynchronize(devs[i]->stream));
+    }
+    return BSGS_OK;
 }
 
 // ---- phase timing: the same batch run with the kernel stopping after phase 1, after phase 2, and in full ------

@@ -56,6 +56,21 @@ struct bsgs_dev {
                                 // per queue with pooled chain scratch (slower sustained: DESIGN.md 8); streamed ping-pong
                                 // kernels 3, 4 (LDS probes), 5 (all loads LDS-staged, counted vmcnt)
     bool timing_open = false;
+    // tile centres of the queued launches, device + pinned staging (grow-only; replaced buffers wait in pending_* for bsgs_collect)
+    fe *cen_dev = nullptr;
+    uint8_t *cen_pin = nullptr;
+    uint64_t cen_cap = 0;                  // tiles
+    // device-side tile walk (bsgs_set_walk): P_k = P0 + k*D ; table = affine 2^j * D, j = 0..63
+    bool walk_set = false;
+    fe walk_p0x, walk_p0y;
+    fe *walk_table = nullptr;
+    // flags (bsgs_set_flags)
+    uint32_t flags = 0;
+    u32 *quirk_list = nullptr;             // device: giants whose Gy trips the reference's NEGMODP (BSGS_FLAG_REFERENCE_QUIRKS)
+    std::vector<uint32_t> quirk_host;      // the same, sorted, for the hit filter of bsgs_collect
+    bool quirk_ready = false;
+    u64 *digest = nullptr;                 // bsgs_run_digest: [tile][Ti][2]
+    uint64_t digest_bytes = 0;
 };
 
 // shared between the translation units of the library

@@ -79,6 +79,9 @@ struct Config {
     uint64_t max_tiles = 0;                        // test hook: stop after this many tiles (0 = unlimited)
     bool ext = false;                              // extended table (bucket lines + overflow list, no HT files); implied by w >= 3069485951
     std::string dir = ".";                         // where table / output files live
+    bool ref_quirks = false;                       // -refquirks: reproduce the reference kernel's NEGMODP bug bit for bit (BSGS_FLAG_REFERENCE_QUIRKS)
+    bool host_centres = false;                     // -hostcentres: tile centres added on the host and uploaded (the reference's way) instead of the device walk
+    std::string joblog;                            // test hook: log every dispenser / checkpoint event to this file
 };
 
 static void die(const std::string &msg)
@@ -101,7 +104,9 @@ static void usage(const Config &c)
            "-htsz    Set number of HashTable 2^ , default %u\n-infile  Set file with pubkey for searching in uncompressed/compressed  format (search sequential)\n"
            "-wl      Set recovery file from which the state will be loaded\n-wt      Set timer for autosaving current state, default every %dseconds\n"
            "-onlygen Generate the table files and exit (onlygen_1_9_6File0.exe)\n-dir     Directory for table files, currentwork.txt and win.txt\n"
-           "-ext     Extended baby table built in GPU memory (no HT files); automatic for -w above the reference limit, up to 2^36\n",
+           "-ext     Extended baby table built in GPU memory (no HT files); automatic for -w above the reference limit, up to 2^36\n"
+           "-refquirks   Reproduce the reference kernel's -Gy borrow bug bit for bit (default: correct arithmetic, finds a superset)\n"
+           "-hostcentres Add the tile centres on the host and upload them (default: derived on the GPU from the tile counter)\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
 }
 
@@ -135,6 +140,9 @@ static Config parse_args(int argc, char **argv)
         else if (a == "-maxtiles") c.max_tiles = strtoull(next().c_str(), nullptr, 10);
         else if (a == "-dir") c.dir = next();
         else if (a == "-ext") c.ext = true;
+        else if (a == "-refquirks") c.ref_quirks = true;
+        else if (a == "-hostcentres") c.host_centres = true;
+        else if (a == "-joblog") c.joblog = next();
         else die("Unknown parameter " + a);
     }
     // limits 1_9_7File.pb:4412-4418, 4616-4618
@@ -180,7 +188,7 @@ struct MiniBsgs {
     std::vector<uint64_t> find(const Affine &T, uint64_t w) const;     // every b' in [1, w] with x(b'G) = x(T)
 };
 
-struct Tile { Scalar key; Affine pub; };
+struct Tile { Scalar key; uint64_t index; };          // counter and dispenser index of a tile: centre = walk_p0 + index * PUBADDBIG
 struct PendingHit { uint32_t code, idx; Tile tile; };
 
 struct Shared {
@@ -191,8 +199,10 @@ struct Shared {
     Affine addpubg, center, pubadd, start_neg;   // -(2w)G ; -(p*w)G ; -(gstep)G ; -(start)G
     Affine realpub, findpub;
     std::mutex job_mutex;
-    Scalar glob_key;
-    Affine glob_pub;
+    Scalar glob_key;                              // counter of the next tile to hand out
+    uint64_t glob_index = 0;                      // its index: counter = key0 + index * gstep
+    Affine walk_p0;                               // centre of tile 0 of this job: Q' - key0*G - C*G (1_9_7File.pb:5056-5064)
+    FILE *joblog = nullptr;
     std::mutex chk_mutex;
     std::condition_variable chk_cv;
     std::deque<PendingHit> checker;
@@ -212,32 +222,40 @@ struct Shared {
     std::string mainpub_hex;
 };
 
-// GetJob for a batch: hand out `n` consecutive tiles (1_9_7File.pb:2077-2092), one normalisation for the batch
-static size_t get_jobs(Shared &S, size_t n, std::vector<Tile> &out)
+// centre of tile `index`: P0 + index * PUBADDBIG (what GetJob accumulates one addition at a time, 1_9_7File.pb:2077-2092)
+static Affine tile_centre(const Shared &S, uint64_t index)
+{
+    if (!index) return S.walk_p0;
+    return hs::point_add(S.walk_p0, hs::point_mul(S.pubadd, hs::fe_from_u64(index)));
+}
+
+// GetJob for a batch: hand out `n` consecutive tiles (1_9_7File.pb:2077-2092).  Only the COUNTER advances on the host; the
+// centres are derived on the GPU from the tile index (bsgs_enqueue_walk), or by tile_centre() under -hostcentres.
+static size_t get_jobs(Shared &S, size_t n, std::vector<Tile> &out, int slot = -1)
 {
     std::lock_guard<std::mutex> lk(S.job_mutex);
     out.clear();
-    std::vector<hs::Jac> jac;
-    hs::Jac cur = hs::to_jac(S.glob_pub);
     Scalar key = S.glob_key;
+    uint64_t index = S.glob_index;
     for (size_t i = 0; i < n; i++) {
         // 1_9_7File.pb:2512-2518 tests the counter AFTER the launch: the first tile whose counter exceeds the width is still
         // searched (a tile reaches 2w*maxnonce - p*w below its counter), then the dispenser closes
         if (S.past_end) break;
         if (S.end_range && hs::fe_cmp(key, S.width) > 0) S.past_end = true;
         if (S.cfg.max_tiles && S.tiles_done.load() + out.size() >= S.cfg.max_tiles) break;
-        Tile t; t.key = key;
+        Tile t; t.key = key; t.index = index;
         out.push_back(t);
-        jac.push_back(cur);
-        cur = hs::jac_add_affine(cur, S.pubadd);
         key = hs::sc_add(key, S.gstep);
+        index++;
     }
     if (out.empty()) return 0;
-    jac.push_back(cur);
-    std::vector<Affine> aff = hs::batch_to_affine(jac);
-    for (size_t i = 0; i < out.size(); i++) out[i].pub = aff[i];
-    S.glob_pub = aff.back();
     S.glob_key = key;
+    S.glob_index = index;
+    if (slot >= 0) {   // the batch is in flight from the moment it leaves the dispenser (checkpoint = min over GPUs, 1_9_7File.pb:3904-3911)
+        std::lock_guard<std::mutex> lk2(S.inflight_mutex);
+        S.inflight[slot] = out[0].key; S.inflight_valid[slot] = true;
+        if (S.joblog) { fprintf(S.joblog, "take %d %llu %zu %s\n", slot, (unsigned long long)out[0].index, out.size(), hs::fe_to_hex(out[0].key).c_str()); fflush(S.joblog); }
+    }
     return out.size();
 }
 
@@ -346,11 +364,12 @@ static bool resolve_hit(const Shared &S, const PendingHit &hit, Scalar &key_out)
         Scalar k = hs::sc_add(base, g); if (try_key(S, k, key_out)) return true;
         k = hs::sc_sub(base, g); return try_key(S, k, key_out);
     }
-    Affine T = hit.tile.pub;
+    const Affine centre = tile_centre(S, hit.tile.index);
+    Affine T = centre;
     if (hit.code != 5) {
         Affine gi = hs::point_mul(S.addpubg, hs::fe_from_u64((uint64_t)hit.idx + 1));
         if (hit.code == 2) gi = hs::affine_neg(gi);
-        T = hs::point_add(hit.tile.pub, gi);
+        T = hs::point_add(centre, gi);
         if (T.inf) return false;
     }
     std::vector<uint64_t> babies;                 // b' with x(b'G) = x(T) as far as the table knows
@@ -395,8 +414,10 @@ static void checker_thread(Shared *S)
 }
 
 // ---- per-GPU driver thread: cuda() 1_9_7File.pb:2095-2553 ---------------------------------------------------------
-// devices are opened and loaded once (1_9_7File.pb:2181-2357) and serve every public key of the run
-static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8_t> &htgpu, const std::vector<uint8_t> &g2)
+// devices are opened and loaded once (1_9_7File.pb:2181-2357) and serve every public key of the run.  Only the first device
+// takes the giants and the table from the host (or builds the extended table); the others receive replicas device-to-device
+// (bsgs_broadcast_tables) instead of the reference's per-GPU upload over PCIe (1_9_7File.pb:2337, 2350).
+static bsgs_dev *open_dev(int gpu)
 {
     bsgs_dev *dev = nullptr;
     CK(bsgs_dev_open(gpu, &dev));
@@ -405,6 +426,12 @@ static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8
     uint64_t fr = 0, tot = 0;
     CK(bsgs_dev_meminfo(dev, &fr, &tot));
     printf("GPU #%d %s memory %.0f/%.0f MB\n", gpu, name, fr / 1048576.0, tot / 1048576.0);
+    return dev;
+}
+static void load_first(const Shared &S, int gpu, bsgs_dev *dev, const std::vector<uint8_t> &htgpu, const std::vector<uint8_t> &g2)
+{
+    uint64_t fr = 0, tot = 0;
+    CK(bsgs_dev_meminfo(dev, &fr, &tot));
     CK(bsgs_upload_g2(dev, g2.data(), S.cfg.t, S.cfg.b, S.cfg.p));
     if (S.cfg.ext) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -418,7 +445,6 @@ static bsgs_dev *open_and_load(const Shared &S, int gpu, const std::vector<uint8
         printf("GPU #%d extended table: %llu items, %.1f GiB in memory, %llu over-full buckets, built in %.1fs\n", gpu, (unsigned long long)S.cfg.w,
                bytes / 1073741824.0, (unsigned long long)ovf, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     } else CK(bsgs_upload_htgpu(dev, htgpu.data(), 1ull << S.cfg.htsz, S.cfg.w, BSGS_TABLE_AUTO));
-    return dev;
 }
 
 static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
@@ -427,25 +453,51 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
     std::vector<Tile> tiles;
     std::vector<uint8_t> centres;
     std::vector<bsgs_hit_ex> hits(65536);
-    while (!S->quit.load()) {
-        const size_t n = get_jobs(*S, batch, tiles);
-        { std::lock_guard<std::mutex> lk(S->inflight_mutex); S->inflight_valid[slot] = n > 0; if (n) S->inflight[slot] = tiles[0].key; }
-        if (!n) break;                                            // end of space for this GPU
+    auto push_hits = [&](const bsgs_hit_ex *h, uint32_t n, const Tile *base) {
+        if (!n) return;
+        std::lock_guard<std::mutex> lk(S->chk_mutex);
+        for (uint32_t i = 0; i < n; i++) S->checker.push_back({h[i].code, h[i].idx, base[h[i].tile]});
+        S->chk_cv.notify_all();
+    };
+    // tiles [i0, i0 + n) of the current batch with centres added on the host and uploaded (the reference's way: -hostcentres, and the
+    // fallback when the device walk meets the point at infinity)
+    auto run_host_centres = [&](size_t i0, size_t n, uint32_t *nh) {
         centres.resize(n * 64);
-        for (size_t i = 0; i < n; i++) hs::affine_to_le(tiles[i].pub, &centres[i * 64], &centres[i * 64 + 32]);
-        uint32_t nh = 0;
-        int rc = bsgs_run(dev, centres.data(), (uint32_t)n, hits.data(), (uint32_t)hits.size(), &nh, nullptr);
-        if (rc != BSGS_OK && rc != BSGS_ERR_OVERFLOW) die(std::string("error bsgs_run-") + std::to_string(rc) + ": " + bsgs_last_error());
-        if (nh) {
-            std::lock_guard<std::mutex> lk(S->chk_mutex);
-            for (uint32_t i = 0; i < std::min<uint32_t>(nh, (uint32_t)hits.size()); i++)
-                S->checker.push_back({hits[i].code, hits[i].idx, tiles[hits[i].tile]});
-            S->chk_cv.notify_all();
+        for (size_t i = 0; i < n; i++) {
+            const Affine c = tile_centre(*S, tiles[i0 + i].index);
+            if (c.inf) die("tile centre is the point at infinity (the public key equals -(counter + p*w)*G): the reference cannot search this tile either");
+            hs::affine_to_le(c, &centres[i * 64], &centres[i * 64 + 32]);
         }
+        return bsgs_run(dev, centres.data(), (uint32_t)n, hits.data(), (uint32_t)hits.size(), nh, nullptr);
+    };
+    while (!S->quit.load()) {
+        const size_t n = get_jobs(*S, batch, tiles, slot);
+        if (!n) break;                                            // end of space for this GPU
+        uint32_t nh = 0;
+        int rc = S->cfg.host_centres ? run_host_centres(0, n, &nh)
+                                     : bsgs_run_walk(dev, tiles[0].index, (uint32_t)n, hits.data(), (uint32_t)hits.size(), &nh, nullptr);
+        if (rc == BSGS_ERR_DEGENERATE) rc = run_host_centres(0, n, &nh);
+        if (rc == BSGS_ERR_OVERFLOW) {
+            // more hits than the buffers hold (a degenerate table: tiny -htsz with a large -w): nothing may be dropped silently --
+            // the true hit could be among the lost records.  Re-run the batch tile by tile.
+            fprintf(stderr, "\nGPU#%d: %u hits in one batch of %zu tiles exceed the hit buffer; re-running tile by tile\n", gpu, nh, n);
+            for (size_t i = 0; i < n; i++) {
+                uint32_t n1 = 0;
+                int r1 = S->cfg.host_centres ? run_host_centres(i, 1, &n1) : bsgs_run_walk(dev, tiles[i].index, 1, hits.data(), (uint32_t)hits.size(), &n1, nullptr);
+                if (r1 == BSGS_ERR_DEGENERATE) r1 = run_host_centres(i, 1, &n1);
+                if (r1 != BSGS_OK) die(std::string("error bsgs_run-") + std::to_string(r1) + ": " + bsgs_last_error() + " (one tile alone overflows the hit buffer: raise -htsz)");
+                push_hits(hits.data(), n1, &tiles[i]);
+            }
+        } else if (rc != BSGS_OK) die(std::string("error bsgs_run-") + std::to_string(rc) + ": " + bsgs_last_error());
+        else push_hits(hits.data(), nh, tiles.data());
         S->steps_done += 2 * S->maxnonce * n;
         S->tiles_done += n;
+        {
+            std::lock_guard<std::mutex> lk(S->inflight_mutex);
+            S->inflight_valid[slot] = false;
+            if (S->joblog) { fprintf(S->joblog, "done %d %llu %zu\n", slot, (unsigned long long)tiles[0].index, n); fflush(S->joblog); }
+        }
     }
-    { std::lock_guard<std::mutex> lk(S->inflight_mutex); S->inflight_valid[slot] = false; }
     printf("GPU#%d job finished\n", gpu);
     { std::lock_guard<std::mutex> lk(S->done_mutex); S->gpus_finished++; }
     S->done_cv.notify_all();
@@ -454,6 +506,23 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
 // ---- Tune (1_9_7File.pb:324-431 prints suggested -t -b -p -w -htsz per GPU from free memory and SM count) ----------
 // MI355X version: the engine re-batches internally, so -t/-b/-p only set the tile size; -w / -htsz follow from HBM:
 // device bytes = 64*2^htsz (bucket lines) + 4*2^htsz + 4*w (htGPU image) + 64*t*b*p (giants) + chain scratch (~8 GiB).
+struct TuneAdvice { double w_log2; uint32_t htsz; bool ext; uint32_t ext_w_log2, ext_htsz; };
+static TuneAdvice tune_advice(uint64_t free_bytes)
+{
+    TuneAdvice a{};
+    const uint64_t budget = free_bytes > (24ull << 30) ? free_bytes - (24ull << 30) : free_bytes / 2;      // giants, chain scratch, hit buffers, slack
+    uint32_t htsz = 20;
+    while (htsz < 31 && (68ull << (htsz + 1)) + (16ull << (htsz + 1)) <= budget) htsz++;     // lines + image at 4 entries per bucket
+    double wl = htsz + 2.0;                                                          // mean bucket load 4
+    const double wmax = std::log2(3069485950.0);                                     // reference format limit (1_9_7File.pb:4412-4418)
+    if (wl > wmax) wl = wmax;
+    a.w_log2 = wl; a.htsz = htsz;
+    // beyond the reference's table format (no HT files): 64-byte bucket lines at 8 entries per bucket, built in GPU memory
+    uint32_t eh = 20;
+    while (eh < 31 && (64ull << (eh + 1)) <= budget) eh++;
+    a.ext = eh + 3 > 31; a.ext_w_log2 = std::min(eh + 3, 36u); a.ext_htsz = eh;
+    return a;
+}
 static void tune(int gpu)
 {
     bsgs_dev *dev = nullptr;
@@ -462,17 +531,9 @@ static void tune(int gpu)
     int cus = 0;
     char name[256] = "";
     bsgs_dev_meminfo(dev, &fr, &tot); bsgs_dev_cu_count(dev, &cus); bsgs_dev_name(dev, name, sizeof name);
-    const uint64_t budget = fr > (24ull << 30) ? fr - (24ull << 30) : fr / 2;      // giants, chain scratch, hit buffers, slack
-    uint32_t htsz = 20;
-    while (htsz < 31 && (68ull << (htsz + 1)) + (16ull << (htsz + 1)) <= budget) htsz++;     // lines + image at 4 entries per bucket
-    double wl = htsz + 2.0;                                                          // mean bucket load 4
-    const double wmax = std::log2(3069485950.0);                                     // reference format limit (1_9_7File.pb:4412-4418)
-    if (wl > wmax) wl = wmax;
-    printf("GPU #%d %s: %d CUs, %.0f MB free -> suggested  -t 256 -b 256 -p 256 -w %.2f -htsz %u\n", gpu, name, cus, fr / 1048576.0, wl, htsz);
-    // beyond the reference's table format (no HT files): 64-byte bucket lines at 8 entries per bucket, built in GPU memory
-    uint32_t eh = 20;
-    while (eh < 31 && (64ull << (eh + 1)) <= budget) eh++;
-    if (eh + 3 > 31) printf("GPU #%d extended table (w above the reference limit): -t 256 -b 256 -p 256 -w %u -htsz %u\n", gpu, std::min(eh + 3, 36u), eh);
+    const TuneAdvice a = tune_advice(fr);
+    printf("GPU #%d %s: %d CUs, %.0f MB free -> suggested  -t 256 -b 256 -p 256 -w %.2f -htsz %u\n", gpu, name, cus, fr / 1048576.0, a.w_log2, a.htsz);
+    if (a.ext) printf("GPU #%d extended table (w above the reference limit): -t 256 -b 256 -p 256 -w %u -htsz %u\n", gpu, a.ext_w_log2, a.ext_htsz);
     bsgs_dev_close(dev);
 }
 
@@ -485,11 +546,16 @@ static std::string fingerprint(const Config &c)
 }
 static void save_checkpoint(Shared &S)
 {
-    // the minimum counter over the GPUs' unfinished batches (a restart re-does at most the batches in flight)
+    // the minimum counter over the GPUs' unfinished batches (a restart re-does at most the batches in flight); both locks are
+    // held so that a batch cannot leave the dispenser between reading its counter and reading the in-flight table
     Scalar cnt;
-    { std::lock_guard<std::mutex> lk(S.job_mutex); cnt = S.glob_key; }
-    { std::lock_guard<std::mutex> lk(S.inflight_mutex);
-      for (size_t g = 0; g < S.inflight.size(); g++) if (S.inflight_valid[g] && hs::fe_cmp(S.inflight[g], cnt) < 0) cnt = S.inflight[g]; }
+    {
+        std::lock_guard<std::mutex> lk(S.job_mutex);
+        std::lock_guard<std::mutex> lk2(S.inflight_mutex);
+        cnt = S.glob_key;
+        for (size_t g = 0; g < S.inflight.size(); g++) if (S.inflight_valid[g] && hs::fe_cmp(S.inflight[g], cnt) < 0) cnt = S.inflight[g];
+        if (S.joblog) { fprintf(S.joblog, "save %s\n", hs::fe_to_hex(cnt).c_str()); fflush(S.joblog); }
+    }
     const std::string tmp = S.cfg.dir + "/currentwork.temp", dst = S.cfg.dir + "/currentwork.txt";
     {
         std::ofstream f(tmp, std::ios::binary);
@@ -533,11 +599,11 @@ static int selftest(int argc, char **argv)
             S.center = hs::affine_neg(hs::point_mul(hs::G, S.center_big));
             S.gstep = hs::sc_mul_small(hs::sc_from_u128((hs::u128)S.maxnonce * S.cfg.w), 4);
             S.pubadd = hs::affine_neg(hs::point_mul(hs::G, S.gstep));
-            S.glob_key = hs::fe_from_u64(1);
-            S.glob_pub = hs::point_add(hs::point_add(pub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
+            S.glob_key = hs::fe_from_u64(1); S.glob_index = 0;
+            S.walk_p0 = hs::point_add(hs::point_add(pub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
             std::vector<Tile> tiles;
             get_jobs(S, n, tiles);
-            for (const Tile &t : tiles) printf("job %s %s\n", hs::fe_to_hex(t.key).c_str(), pt(t.pub).c_str());
+            for (const Tile &t : tiles) printf("job %s %s\n", hs::fe_to_hex(t.key).c_str(), pt(tile_centre(S, t.index)).c_str());
         } else if (a[i] == "minibsgs" && i + 2 < a.size()) {                 // w (decimal), then hex scalars m: all b' <= w with x(b'G) = x(mG)
             const uint64_t w = strtoull(a[++i].c_str(), nullptr, 10);
             MiniBsgs mb; mb.build(w, 4);
@@ -548,6 +614,20 @@ static int selftest(int argc, char **argv)
                 for (uint64_t b : mb.find(hs::point_mul(hs::G, m), w)) out += " " + std::to_string(b);
                 printf("find %s%s\n", a[i].c_str(), out.c_str());
             }
+        } else if (a[i] == "tune" && i + 1 < a.size()) {                      // free bytes -> the MI355X sizing advice (replaces Tune, 1_9_7File.pb:324-431)
+            const TuneAdvice t = tune_advice(strtoull(a[++i].c_str(), nullptr, 10));
+            printf("tune -w %.2f -htsz %u ext %d -w %u -htsz %u\n", t.w_log2, t.htsz, t.ext ? 1 : 0, t.ext_w_log2, t.ext_htsz);
+        } else if (a[i] == "checkpoint" && i + 1 < a.size()) {                // next counter, then in-flight counters ("-" = idle GPU): the saved one
+            Shared S;
+            if (!hs::fe_from_hex(S.glob_key, a[++i])) return 2;
+            for (++i; i < a.size(); i++) {
+                Scalar v = hs::fe_from_u64(0);
+                const bool valid = a[i] != "-";
+                if (valid && !hs::fe_from_hex(v, a[i])) return 2;
+                S.inflight.push_back(v); S.inflight_valid.push_back(valid);
+            }
+            S.cfg.dir = "/tmp"; S.mainpub_hex = "selftest"; S.joblog = stdout;
+            save_checkpoint(S);
         } else { fprintf(stderr, "selftest: unknown item %s\n", a[i].c_str()); return 2; }
     }
     return 0;
@@ -617,11 +697,17 @@ int main(int argc, char **argv)
     // ---- range (1_9_7File.pb:4887-4943)
     if (!hs::fe_from_hex(S.start, c.pk) || hs::fe_is_zero(S.start)) die("Start range can`t be zero");
     printf("START RANGE= %s\n", hs::fe_to_hex(S.start).c_str());
-    if (c.pke_given) {
+    {   // the end of range is ALWAYS in force: privkeyend defaults to 1ffffffffffffffff and endrangeflag is set whenever it is
+        // non-zero (1_9_7File.pb:210, 4897-4936); a key outside [pk, pke] ends with "Reached end of space"
         Scalar e;
-        if (!hs::fe_from_hex(e, c.pke) || hs::fe_cmp(e, S.start) <= 0) die("End range should be more than begin range!");
-        S.width = hs::sc_sub(e, S.start); S.end_range = true;
-        printf("  END RANGE= %s\nWIDTH RANGE= %s\n", hs::fe_to_hex(e).c_str(), hs::fe_to_hex(S.width).c_str());
+        if (!hs::fe_from_hex(e, c.pke)) die("Invalid range (-pkend) length!!!");
+        if (!hs::fe_is_zero(e)) {
+            if (hs::fe_cmp(e, S.start) <= 0) die(c.pke_given ? "End range should be more than begin range!" : "End range must be more then start range");
+            S.width = hs::sc_sub(e, S.start); S.end_range = true;
+            int bits = 0;
+            for (int l = 3; l >= 0 && !bits; l--) if (S.width.l[l]) bits = 64 * l + 64 - __builtin_clzll(S.width.l[l]);
+            printf("  END RANGE= %s\nWIDTH RANGE= %s = 2^%d\n", hs::fe_to_hex(e).c_str(), hs::fe_to_hex(S.width).c_str(), bits);
+        }
     }
     S.start_neg = hs::affine_neg(hs::point_mul(hs::G, S.start));
 
@@ -652,11 +738,18 @@ int main(int argc, char **argv)
         printf("Resolver table: 2^%u multiples of G in %.1fs\n", S.mini.mb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     std::vector<bsgs_dev *> devs(gpus.size(), nullptr);
-    {   // one loader thread per GPU (each builds / uploads its own replica; 1_9_7File.pb:4769-4843 starts them the same way)
-        std::vector<std::thread> ld;
-        for (size_t gi = 0; gi < gpus.size(); gi++) ld.emplace_back([&, gi]() { devs[gi] = open_and_load(S, gpus[gi], htgpu, g2); });
-        for (auto &x : ld) x.join();
+    {   // the first GPU takes the giants and the table from the host (or builds the extended table); every other GPU -- the same id may
+        // be listed twice: two engines, two driver threads on one GPU -- gets its replica device-to-device over xGMI
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t gi = 0; gi < gpus.size(); gi++) devs[gi] = open_dev(gpus[gi]);
+        load_first(S, gpus[0], devs[0], htgpu, g2);
+        if (devs.size() > 1) {
+            CK(bsgs_broadcast_tables(devs.data(), (int)devs.size()));
+            printf("Tables replicated to %zu more GPU engine(s) device-to-device in %.2fs\n", devs.size() - 1, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+        if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }
     }
+    if (!c.joblog.empty()) { S.joblog = fopen(c.joblog.c_str(), "w"); if (!S.joblog) die("Can`t create " + c.joblog); }
     std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
     std::vector<uint8_t>().swap(g2);
 
@@ -673,7 +766,14 @@ int main(int argc, char **argv)
         // dispenser seed (1_9_7File.pb:5046-5064)
         S.glob_key = hs::fe_from_u64(1);
         if (recovery) { if (!hs::fe_from_hex(S.glob_key, rec_cnt)) die("bad counter"); recovery = false; }
-        S.glob_pub = hs::point_add(hs::point_add(S.findpub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
+        S.glob_index = 0;
+        S.walk_p0 = hs::point_add(hs::point_add(S.findpub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
+        if (!c.host_centres) {
+            if (S.walk_p0.inf) die("the public key equals (counter + p*w)*G: the first tile centre is the point at infinity");
+            uint8_t p0[64], st[64];
+            hs::affine_to_le(S.walk_p0, p0, p0 + 32); hs::affine_to_le(S.pubadd, st, st + 32);
+            for (bsgs_dev *d : devs) CK(bsgs_set_walk(d, p0, st));      // from here on the host only advances the counter
+        }
         S.past_end = false;
         S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0;
         const auto t0 = std::chrono::steady_clock::now();
@@ -702,7 +802,7 @@ int main(int argc, char **argv)
                     fflush(stdout);
                     last_steps = st; last_t = now;
                 }
-                if (std::chrono::duration<double>(now - last_save).count() >= c.wt) { save_checkpoint(S); last_save = now; }
+                if (std::chrono::duration<double>(now - last_save).count() >= c.wt || S.joblog) { save_checkpoint(S); last_save = now; }
             }
             for (auto &x : th) x.join();
             // drain the checker queue, then stop it
@@ -723,6 +823,7 @@ int main(int argc, char **argv)
         printf("Job time %.2fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)S.tiles_done.load(), (double)S.steps_done.load());
     }
     for (bsgs_dev *d : devs) bsgs_dev_close(d);
+    if (S.joblog) fclose(S.joblog);
     printf("Found %d of %zu\n", finditems, pubs.size());
     return 0;
 }

@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("BSGS_LIB_PATH") or os.path.join(PKG_ROOT, "build", "l
 
 TABLE_AUTO, TABLE_CSR, TABLE_LINES64, TABLE_LINES128, TABLE_LINES64_LIST, TABLE_LINES128_LIST = 0, 1, 2, 3, 4, 5
 ERR_OVERFLOW = -5
+ERR_DEGENERATE = -6
+FLAG_REFERENCE_QUIRKS = 1
 
 # every symbol include/bsgs_hip.h declares (checked by tests/test_abi.py)
 NATIVE_SYMBOLS = [
@@ -21,6 +23,8 @@ NATIVE_SYMBOLS = [
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
+    "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -88,6 +92,15 @@ def lib():
             "bsgs_build_baby_table_ext_device": [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
             "bsgs_install_table_ext_device": [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32],
             "bsgs_profile_phases": [vp, u8p, C.c_uint32, C.POINTER(C.c_float)],
+            "bsgs_set_walk": [vp, u8p, u8p],
+            "bsgs_enqueue_walk": [vp, C.c_uint64, C.c_uint32],
+            "bsgs_run_walk": [vp, C.c_uint64, C.c_uint32, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)],
+            "bsgs_walk_centres": [vp, C.c_uint64, C.c_uint32, vp],
+            "bsgs_set_flags": [vp, C.c_uint32],
+            "bsgs_broadcast_tables": [C.POINTER(vp), C.c_int],
+            "bsgs_tiles_per_launch": [vp, C.POINTER(C.c_uint32)],
+            "bsgs_engine_geometry": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+            "bsgs_run_digest": [vp, u8p, C.c_uint32, vp, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -227,6 +240,50 @@ class Device:
 
     def set_tiles_per_launch(self, n):
         _chk(self.L.bsgs_set_tiles_per_launch(self.h, n))
+
+    def tiles_per_launch(self):
+        n = C.c_uint32()
+        _chk(self.L.bsgs_tiles_per_launch(self.h, C.byref(n)))
+        return n.value
+
+    def engine_geometry(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        _chk(self.L.bsgs_engine_geometry(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_flags(self, flags):
+        _chk(self.L.bsgs_set_flags(self.h, flags))
+
+    # ---- device-side tile walk: centre of tile k = P0 + k*stride, derived on the GPU ----
+    def set_walk(self, p0, stride):
+        _chk(self.L.bsgs_set_walk(self.h, le32(p0[0]) + le32(p0[1]), le32(stride[0]) + le32(stride[1])))
+
+    def enqueue_walk(self, first, ntiles):
+        _chk(self.L.bsgs_enqueue_walk(self.h, first, ntiles))
+
+    def run_walk(self, first, ntiles, max_hits=65536):
+        hits = (HitEx * max_hits)()
+        n, ms = C.c_uint32(), C.c_float()
+        _chk(self.L.bsgs_run_walk(self.h, first, ntiles, hits, max_hits, C.byref(n), C.byref(ms)), allow_overflow=True)
+        return [(hits[i].tile, hits[i].code, hits[i].idx) for i in range(min(n.value, max_hits))], n.value, ms.value
+
+    def walk_centres(self, first, ntiles):
+        out = C.create_string_buffer(64 * ntiles)
+        _chk(self.L.bsgs_walk_centres(self.h, first, ntiles, C.cast(out, C.c_void_p)))
+        r = out.raw
+        return [(int.from_bytes(r[64 * k:64 * k + 32], "little"), int.from_bytes(r[64 * k + 32:64 * k + 64], "little")) for k in range(ntiles)]
+
+    def run_digest(self, centres, max_hits=65536):
+        """like run(); also returns per (tile, engine thread) the (xor, sum) of every 64-bit key probed"""
+        import numpy as np
+        ntiles = len(centres)
+        threads, _ = self.engine_geometry()
+        blob = b"".join(le32(x) + le32(y) for x, y in centres)
+        dg = np.zeros((ntiles, threads, 2), dtype=np.uint64)
+        hits = (HitEx * max_hits)()
+        n = C.c_uint32()
+        _chk(self.L.bsgs_run_digest(self.h, blob, ntiles, dg.ctypes.data_as(C.c_void_p), hits, max_hits, C.byref(n)), allow_overflow=True)
+        return dg, [(hits[i].tile, hits[i].code, hits[i].idx) for i in range(min(n.value, max_hits))], n.value
 
     def launch_count(self):
         n = C.c_uint64()

@@ -52,7 +52,7 @@ class Job(C.Structure):
 
 def build():
     """(Re)build liboracle.so with gcc if it is missing or older than its sources."""
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("curve64_ref.c", "bsgs_ref.c", "curve64_ref.h", "bsgs_ref.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("curve64_ref.c", "bsgs_ref.c", "cpu_fast.c", "curve64_ref.h", "bsgs_ref.h")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return _SO
@@ -96,6 +96,11 @@ def lib():
                                         C.c_uint32, C.POINTER(Hit), C.c_uint64]),
             "o_tile_ref_slice": (C.c_uint64, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint64,
                                               C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Hit), C.c_uint64]),
+            "o_tile_ref_slice_digest": (C.c_uint64, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint64,
+                                                     C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Hit), C.c_uint64, u8p]),
+            "o_fast_unpack_g2": (None, [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, u8p]),
+            "o_fast_tile_slice_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p, C.c_uint64, C.c_int,
+                                               C.POINTER(C.c_uint64)]),
             "o_tile_xs": (C.c_int, [ppt, ppt, C.c_uint32, pfe, pfe, pfe]),
             "o_job_init": (C.c_int, [C.POINTER(Job), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.c_uint32, pfe, ppt, pfe]),
@@ -196,3 +201,31 @@ def tile_xs(P, Gpt, flags=0):
     eq = lib().o_tile_xs(C.byref(Pt.from_ints(*P)), C.byref(Pt.from_ints(*Gpt)), flags,
                          C.byref(xm), C.byref(xp), C.byref(xd))
     return eq, xm.to_int(), xp.to_int(), xd.to_int()
+
+
+def tile_slice_digest(P, g2buf, t, b, p, htbuf, htsz, tid0, tid1, flags=0, max_hits=4096):
+    """threads [tid0, tid1) of a tile: (sorted hits [(code, idx)], total, digest uint64[(tid1-tid0), 2]); g2buf / htbuf are
+    ctypes buffers or numpy arrays (htbuf may be None: digest only)"""
+    import numpy as np
+    hits = (Hit * max_hits)()
+    dg = np.zeros((tid1 - tid0, 2), dtype=np.uint64)
+    ptr = lambda x: None if x is None else (x.ctypes.data_as(C.c_void_p) if hasattr(x, "ctypes") else C.cast(x, C.c_void_p))  # noqa: E731
+    n = lib().o_tile_ref_slice_digest(C.byref(Pt.from_ints(*P)), ptr(g2buf), t, b, p, ptr(htbuf), 1 << htsz, flags,
+                                      tid0, tid1, hits, max_hits, dg.ctypes.data_as(C.c_void_p))
+    return [(hits[i].code, hits[i].idx) for i in range(min(n, max_hits))], n, dg
+
+
+def fast_tile_slice(P, g2buf, t, b, p, htbuf, htsz, tid0, tid1, nthreads=1):
+    """the best-effort CPU baseline (oracle/cpu_fast.c) over threads [tid0, tid1): (hits, digest_xor, digest_sum, seconds of
+    the tile work only -- the giants are unpacked before the clock starts)"""
+    import time
+    import numpy as np
+    ptr = lambda x: None if x is None else (x.ctypes.data_as(C.c_void_p) if hasattr(x, "ctypes") else C.cast(x, C.c_void_p))  # noqa: E731
+    count = (tid1 - tid0) * p
+    plain = np.empty(8 * count, dtype=np.uint64)
+    lib().o_fast_unpack_g2(ptr(g2buf), t, b, p, tid0 * p, count, plain.ctypes.data_as(C.c_void_p))
+    out = (C.c_uint64 * 3)()
+    t0 = time.time()
+    lib().o_fast_tile_slice_mt(C.byref(Pt.from_ints(*P)), plain.ctypes.data_as(C.c_void_p), tid0 * p, p, tid0, tid1, ptr(htbuf),
+                               1 << htsz, nthreads, out)
+    return int(out[0]), int(out[1]), int(out[2]), time.time() - t0

@@ -3,6 +3,9 @@
 (the file bench.py reads for roofline.traffic and the ALU-side figures).
 
   tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/<tag>_pmc_traffic.json [steps_per_launch]
+
+The configuration the passes ran on is read from <dir>/bench_under_rocprofv3_stats.json (the bench line of the same
+command) and stored under "config": bench.py reports the per-step figures only for a run of that configuration.
 """
 import csv
 import json
@@ -59,6 +62,22 @@ def main():
     i64, _, _ = pick(d, "SQ_INSTS_VALU_INT64", prod)
     if i64:
         res["valu_int64_instructions_per_step"] = i64 * 64 / steps
+    try:                                                # which configuration was profiled (bench.py compares it with its own run)
+        line = [x for x in open(os.path.join(d, "bench_under_rocprofv3_stats.json")).read().splitlines() if x.startswith("{")][-1]
+        bj = json.loads(line)
+        wl = bj["config"]["workload"].split()
+        cfg = {"t": int(wl[1]), "b": int(wl[3]), "p": int(wl[5]), "w": float(wl[7]), "htsz": int(wl[9].rstrip(":")),
+               "layout": bj["config"]["table_layout"], "variant": os.environ.get("BSGS_KERNEL_VARIANT", "10")}
+        res["config"] = cfg
+        res["steps_per_launch"] = steps = int(bj["roofline"]["algorithmic_bytes_per_launch"] / 64)
+        for k in ("fetch", "write"):
+            res["%s_bytes_per_step" % k] = res["%s_bytes_per_launch" % k] / steps
+        if valu:
+            res["valu_instructions_per_step"] = valu * 64 / steps
+        if i64:
+            res["valu_int64_instructions_per_step"] = i64 * 64 / steps
+    except Exception as e:
+        res["config_error"] = repr(e)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res)[:600])
 

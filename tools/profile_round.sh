@@ -16,7 +16,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "VALUBusy" "SALUBusy" "MemUnitStalled" "MeanOccupancyPerCU" \
            "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1)); name=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --output-format csv -d /tmp/rp/pmc$i -- python $R/bench.py --no-cpu-baseline --steps 96 --warmup 48 "$@" > /dev/null 2> /tmp/rp/pmc$i.err \
+  rocprofv3 --pmc $grp --output-format csv -d /tmp/rp/pmc$i -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > /dev/null 2> /tmp/rp/pmc$i.err \
     && python $R/tools/rocprof_summary.py pmc /tmp/rp/pmc$i $OUT/rocprofv3_pmc_$name.csv > /dev/null || { echo "pass $name failed"; tail -3 /tmp/rp/pmc$i.err; }
 done
 grep -h "giant_\|gups" $OUT/rocprofv3_pmc_*.csv | sed 's/^"[^"]*",//' | sort | uniq | head -80
