@@ -994,6 +994,28 @@ extern "C" int bsgs_selftest_fe(bsgs_dev *d, int op, const uint8_t *a, const uin
     return BSGS_OK;
 }
 
+// the low-64-bit squaring path against the full-width one on n*iters pseudo-random cases: counts[0] mismatches (must be 0),
+// counts[1] cases that took the exact path, counts[2] cases
+extern "C" int bsgs_selftest_lo64(bsgs_dev *d, const uint8_t *a, const uint8_t *b, uint32_t n, uint32_t iters, uint64_t counts[3])
+{
+    if (!d || !a || !b || !counts || !n) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    fe *da = nullptr, *db = nullptr; unsigned long long *dc = nullptr;
+    HIPCHK(hipMalloc(&da, (size_t)n * 32)); HIPCHK(hipMalloc(&db, (size_t)n * 32)); HIPCHK(hipMalloc(&dc, 24));
+    HIPCHK(hipMemcpy(da, a, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, (size_t)n * 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dc, 0, 24));
+    hipLaunchKernelGGL(lo64_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, da, db, dc, n, iters);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, dc, 24, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dc);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "selftest_lo64: %s", hipGetErrorString(e));
+    counts[0] = h[0]; counts[1] = h[1]; counts[2] = h[2];
+    return BSGS_OK;
+}
+
 extern "C" int bsgs_selftest_xs(bsgs_dev *d, const uint8_t px_le[32], const uint8_t py_le[32], uint64_t first, uint32_t count, uint8_t *out)
 {
     if (!d || !px_le || !py_le || !out) return fail(BSGS_ERR_ARG, "null");

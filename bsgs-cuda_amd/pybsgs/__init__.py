@@ -24,7 +24,7 @@ NATIVE_SYMBOLS = [
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
-    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -101,6 +101,7 @@ def lib():
             "bsgs_tiles_per_launch": [vp, C.POINTER(C.c_uint32)],
             "bsgs_engine_geometry": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
             "bsgs_run_digest": [vp, u8p, C.c_uint32, vp, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32)],
+            "bsgs_selftest_lo64": [vp, u8p, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -307,6 +308,13 @@ class Device:
         out = C.create_string_buffer(32 * n)
         _chk(self.L.bsgs_selftest_fe(self.h, op, a, b, C.cast(out, C.c_void_p), n))
         return [int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(n)]
+
+    def selftest_lo64(self, a_list, b_list, iters):
+        """(mismatches, exact-path cases, cases) of the low-64 squaring path vs the full-width arithmetic"""
+        n = len(a_list)
+        out = (C.c_uint64 * 3)()
+        _chk(self.L.bsgs_selftest_lo64(self.h, b"".join(le32(v) for v in a_list), b"".join(le32(v) for v in b_list), n, iters, out))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def selftest_xs(self, px, py, first, count):
         out = C.create_string_buffer(96 * count)

@@ -158,3 +158,118 @@ def test_key_in_the_last_tile_of_a_range(tmp_path):
     out = run(["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14", "-pb", "%064x%064x" % ecpy.mul(start + width + 3 * 2**31),
                "-pk", "%x" % start, "-pke", "%x" % (start + width)], tmp_path)
     assert "Reached end of space" in out and "Found 0 of 1" in out
+
+
+def test_default_end_range_applies_without_pke(tmp_path):
+    """the reference always has an end of range: -pke defaults to 1ffffffffffffffff (1_9_7File.pb:210, 4897-4936).  A key
+    beyond it ends the job with "Reached end of space" instead of searching forever; an -infile job moves on to the next key."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    geo = ["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14"]
+    pk = 0x1ffffffffff000000                                     # 2^24 below the default end (2^65 - 1)
+    inside, outside = pk + 0x123456, pk + 2**40
+    infile = tmp_path / "pubs.txt"
+    infile.write_text("%064x%064x\n%064x%064x\n" % (ecpy.mul(outside) + ecpy.mul(inside)))
+    out = run(geo + ["-infile", str(infile), "-pk", "%x" % pk], tmp_path, timeout=120)
+    assert "END RANGE= %064x" % 0x1ffffffffffffffff in out and "WIDTH RANGE=" in out
+    assert out.count("Reached end of space") == 1 and "Found 1 of 2" in out
+    assert win_lines(tmp_path)[0] == "KEY[2]: 0x%064x" % inside
+    # the reference's check of the start against the (default) end
+    res = subprocess.run([EXE, "-dir", str(tmp_path)] + geo + ["-pb", PUB_65BIT, "-pk", "2ffffffffffffffff"], capture_output=True, text=True)
+    assert res.returncode != 0 and "End range" in res.stderr
+
+
+def test_two_engines_share_one_dispenser_and_checkpoint_is_min_in_flight(tmp_path):
+    """-d 0,0: two driver threads (two engines, the second one a device-to-device replica of the first) share the GetJob
+    dispenser (1_9_7File.pb:2077-2092, 4769-4815).  Every tile is handed out exactly once, both threads work, every
+    checkpoint equals the smallest counter in flight (1_9_7File.pb:3904-3911), and the key is found."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    t, b, p, w = 64, 8, 16, 1 << 16
+    gstep = 4 * t * b * p * w
+    key = 1 + 3000 * gstep + 12345                               # ~3000 tiles = ~63 batches of 48
+    log = tmp_path / "jobs.log"
+    out = run(["-t", str(t), "-b", str(b), "-p", str(p), "-w", "16", "-htsz", "14", "-pb", "%064x%064x" % ecpy.mul(key), "-pk", "1",
+               "-d", "0,0", "-joblog", str(log)], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x%064x" % key
+    assert "replicated to 1 more GPU engine" in out and out.count("job finished") == 2
+    taken, inflight, slots, next_cnt, saves = [], {}, set(), 1, 0
+    for line in log.read_text().splitlines():
+        f = line.split()
+        if f[0] == "take":
+            slot, first, n, cnt = int(f[1]), int(f[2]), int(f[3]), int(f[4], 16)
+            assert cnt == 1 + first * gstep and first == (taken[-1][0] + taken[-1][1] if taken else 0)   # consecutive, no gap, no overlap
+            taken.append((first, n))
+            inflight[slot] = cnt
+            slots.add(slot)
+            next_cnt = cnt + n * gstep
+        elif f[0] == "done":
+            inflight.pop(int(f[1]))
+        elif f[0] == "save":
+            saves += 1
+            assert int(f[1], 16) == min(list(inflight.values()) + [next_cnt])
+    assert slots == {0, 1} and saves > 0
+    assert sum(n for _, n in taken) >= 3000 and taken[0][0] == 0
+
+
+def test_puzzle64_at_config2_flags(tmp_path):
+    """BASELINE config 2 at its exact flags: -t 256 -b 256 -p 256 -w 26 -htsz 25 on the puzzle-64 vector
+    (1_9_7File.pb:200-203); the measured time-to-solve is printed and, on the GPU box, recorded under gpurun_out/."""
+    import time
+    geo = ["-t", "256", "-b", "256", "-p", "256", "-w", "26", "-htsz", "25"]
+    run(geo + ["-onlygen"], tmp_path)                            # table + giants files first: the solve below loads them
+    t0 = time.time()
+    out = run(geo + ["-pb", PUB_PUZZLE64, "-pk", "8000000000000000", "-pke", "ffffffffffffffff"], tmp_path)
+    wall = time.time() - t0
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0xf7051f27b09112d4
+    job = [l for l in out.splitlines() if l.startswith("Job time")][0].split()
+    job_s, tiles = float(job[2].rstrip("s,")), int(job[3])
+    assert tiles >= (0xf7051f27b09112d4 - 0x8000000000000000) // (4 * 2**24 * 2**26) and job_s < 30
+    rec = {"config": " ".join(geo), "key": "0xf7051f27b09112d4", "job_time_s": job_s, "tiles": tiles, "giant_steps": tiles * 2**25,
+           "giant_steps_per_s": tiles * 2**25 / job_s, "process_wall_s_including_file_load_and_upload": wall}
+    print("puzzle64 at config-2 flags:", json.dumps(rec))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "puzzle64_config2.json"), "w") as f:
+            json.dump(rec, f)
+    except OSError:
+        pass
+
+
+def test_config4_true_flags_100_keys(tmp_path):
+    """BASELINE config 4 at its true flags (-t 256 -b 256 -p 256 -w 30 -htsz 28): 100 public keys searched sequentially over the
+    fixed 64-bit range, devices loaded once, the dispenser re-seeded per key"""
+    import sys
+    import time
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < 60 * 2**30:
+        pytest.skip("needs ~40 GiB of free HBM")
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    keys, st = [], 0xC0FFEE4
+    for _ in range(100):
+        st, r = ecpy.splitmix64(st)
+        keys.append((1 << 63) + (r >> 1))
+    infile = tmp_path / "pubs.txt"
+    G2k = {}
+    lines = []
+    for k in keys:
+        x, y = ecpy.mul(k)
+        lines.append(("03" if y & 1 else "02") + "%064x" % x)      # compressed form: exercises the decompression path too
+    infile.write_text("\n".join(lines) + "\n")
+    t0 = time.time()
+    out = run(["-t", "256", "-b", "256", "-p", "256", "-w", "30", "-htsz", "28", "-infile", str(infile),
+               "-pk", "8000000000000000", "-pke", "ffffffffffffffff"], tmp_path, timeout=1500)
+    wall = time.time() - t0
+    got = [int(l.split("0x")[1], 16) for l in win_lines(tmp_path) if l.startswith("KEY[")]
+    assert got == keys
+    job_times = [float(l.split()[2].rstrip("s,")) for l in out.splitlines() if l.startswith("Job time")]
+    rec = {"keys": len(keys), "found": len(got), "wall_s": wall, "sum_job_time_s": sum(job_times), "max_job_time_s": max(job_times)}
+    print("config 4 (true flags, 100 keys):", json.dumps(rec))
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "config4_100keys.json"), "w") as f:
+            json.dump(rec, f)
+    except OSError:
+        pass

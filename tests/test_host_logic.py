@@ -89,3 +89,25 @@ def test_table_free_resolver():
     out = selftest("minibsgs", w, *["%x" % m for m in ms])
     for m, o in zip(ms, out[1:]):
         assert [int(v) for v in o[2:]] == sorted({b for b in (m, N - m) if 1 <= b <= w}), hex(m)
+
+
+def test_tune_advice_for_mi355x():
+    """the MI355X replacement of Tune (1_9_7File.pb:324-431 sizes -t/-b/-p/-w from free memory and SM count): -w / -htsz from
+    free HBM; a 288 GB part is offered the extended table (-w 34 -htsz 31), small parts stay inside the reference format"""
+    out = selftest("tune", 290 * 10**9, "tune", 25 * 10**9, "tune", 8 * 10**9)
+    big, mid, small = out
+    assert big[:5] == ["tune", "-w", "31.52", "-htsz", "31"] and big[5:] == ["ext", "1", "-w", "34", "-htsz", "31"]
+    assert mid[:5] == ["tune", "-w", "29.00", "-htsz", "27"] and mid[6] == "0"
+    assert small[:5] == ["tune", "-w", "27.00", "-htsz", "25"] and small[6] == "0"
+    # the advice never exceeds the reference's table-format limit (1_9_7File.pb:4412-4418) nor the memory it was given
+    for o, free in ((big, 290e9), (mid, 25e9), (small, 8e9)):
+        w, htsz = 2 ** float(o[2]), int(o[4])
+        assert w < 3069485951 * 1.005 and 64 * 2**htsz + 4 * 2**htsz + 4 * w < free       # (-w is printed with two decimals)
+
+
+def test_checkpoint_is_the_minimum_in_flight_counter():
+    """saveCurentCNT (1_9_7File.pb:3897-3931): the saved counter is the smallest one any GPU has not finished, or the
+    dispenser's next counter when all GPUs are idle"""
+    assert selftest("checkpoint", "0901", "0301", "-", "0601")[0] == ["save", "%064x" % 0x301]
+    assert selftest("checkpoint", "0901", "-", "-")[0] == ["save", "%064x" % 0x901]
+    assert selftest("checkpoint", "0901", "0a01", "0b01")[0] == ["save", "%064x" % 0x901]
