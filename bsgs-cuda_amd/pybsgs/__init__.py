@@ -31,6 +31,11 @@ COMPAT_SYMBOLS = [
     "cuDeviceGetAttribute", "cuCtxCreate_v2", "cuCtxDestroy_v2", "cuCtxSynchronize", "cuMemGetInfo_v2", "cuModuleLoadData",
     "cuModuleGetFunction", "cuModuleGetGlobal_v2", "cuFuncSetCacheConfig", "cuFuncSetBlockShape", "cuParamSetSize",
     "cuParamSeti", "cuMemAlloc_v2", "cuMemFree_v2", "cuMemcpyHtoD_v2", "cuMemcpyDtoH_v2", "cuLaunchGrid",
+    # declared by the reference's Import block but never called by v1.9.7 (exported so that the unchanged block links)
+    "cuDeviceTotalMem", "cuCtxCreate", "cuCtxDestroy", "cuMemAlloc", "cuMemFree", "cuMemcpyHtoD", "cuMemcpyDtoH", "cuModuleGetGlobal",
+    "cuModuleLoad", "cuParamSetv", "cuLaunchGridAsync", "cuLaunch", "cuFuncSetSharedSize", "cuFuncGetAttribute", "cuGetErrorName",
+    "cuEventCreate", "cuEventDestroy", "cuEventQuery", "cuEventRecord", "cuEventSynchronize", "cuStreamCreate", "cuStreamCreate_v2",
+    "cuStreamDestroy", "cuStreamSynchronize", "cuStreamQuery",
 ]
 
 
