@@ -70,7 +70,7 @@ static void free_table(bsgs_dev *d)
     if (d->csr && d->csr_owned) (void)hipFree(d->csr);
     if (d->lines && d->lines_owned) (void)hipFree(d->lines);
     if (d->ovf && d->lines_owned) (void)hipFree(d->ovf);
-    d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true;
+    d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true; d->auto_tpl = 0;
 }
 void bsgs_free_table(bsgs_dev *d) { free_table(d); }
 static void free_g2(bsgs_dev *d)
@@ -184,7 +184,7 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     if (T >= (1ull << 31) || maxnonce >= (1ull << 32)) return fail(BSGS_ERR_ARG, "t*b*p must be < 2^32 (hit index is u32)");
     HIPCHK(hipSetDevice(d->id));
     free_g2(d);
-    d->t = t; d->b = b; d->p = p; d->T = T; d->maxnonce = maxnonce;
+    d->t = t; d->b = b; d->p = p; d->T = T; d->maxnonce = maxnonce; d->auto_tpl = 0;
     // Internal batching: one Fermat inversion (270 multiplications) is shared by pi giants of a thread, so a
     // longer batch is cheaper per giant step; the thread count lost that way is won back by putting more tiles
     // in one launch.  Grow pi up to ~2048 while Ti stays a multiple of 256 threads and >= 2048.
@@ -220,13 +220,24 @@ static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
 static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
 {
     if (d->tiles_per_launch) return d->tiles_per_launch;
-    // 4 waves per SIMD fill the chip; with two alternating streams each launch carries half of that, so the
-    // next launch's blocks start as the previous one's drain (no tail between launches)
-    // single stream: three rounds of blocks per launch (ramp + tail cost ~1 ms per launch: 16 / 32 / 48 tiles measured
-    // 31.8 / 33.6 / 34.6 G steps/s; 48 tiles x 64-byte centres is what fits the 4 KiB of kernel arguments)
+    if (d->auto_tpl) return d->auto_tpl;
+    // One launch = three rounds of resident blocks at least (4 waves per SIMD fill the chip): 48 tiles of 16384 engine threads.
+    // A launch boundary (ramp: every resident block in the streaming-bound prefix phase; tail) costs ~1.5 ms, i.e. 3.5 % at 48
+    // tiles (44.7 ms); the centres live in device memory, so nothing but the chain scratch (16 bytes x giants per tile in flight)
+    // limits a launch: measured 36.0 / 37.3 / 37.5 G giant-steps/s at 48 / 96 / 192 tiles (profiles/r02a_ab_tiles_per_launch.log).
+    // Take 4x the fill-the-chip figure when that scratch fits in a third of the free memory, else 2x, else 1x.
     const uint64_t want = (uint64_t)d->prop.multiProcessorCount * (d->nstreams == 2 ? 512 : 3072);
-    uint64_t n = (want + d->Ti - 1) / d->Ti;
-    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(n, 1), BSGS_TILES_PER_LAUNCH);
+    uint64_t n = std::min<uint64_t>(std::max<uint64_t>((want + d->Ti - 1) / d->Ti, 1), BSGS_TILES_PER_LAUNCH);
+    size_t fr = 0, tot = 0;
+    const bool halfchain = (d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
+    const uint64_t per_giant = halfchain ? 16 : 32;             // as ensure_chain sizes the scratch
+    if (d->nstreams == 1 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        fr += d->chain_bytes;                                   // what is already ours counts as available
+        for (uint64_t mult = 4; mult > 1; mult /= 2)
+            if (n * mult <= BSGS_TILES_PER_LAUNCH_MAX && n * mult * d->maxnonce * per_giant <= fr / 3) { n *= mult; break; }
+    }
+    const_cast<bsgs_dev *>(d)->auto_tpl = (uint32_t)n;           // decided once per geometry / table (reset by set_geometry, free_table)
+    return (uint32_t)n;
 }
 
 extern "C" int bsgs_upload_g2_device(bsgs_dev *d, const void *dimage, uint32_t t, uint32_t b, uint32_t p)

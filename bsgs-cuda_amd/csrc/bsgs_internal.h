@@ -49,6 +49,7 @@ struct bsgs_dev {
     uint32_t max_hits = 1u << 16;
     uint32_t queued = 0;
     uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
+    uint32_t auto_tpl = 0;                 // the automatic choice, made once the giants and the table are resident (memory permitting: 4x)
     uint64_t launches = 0;
     int variant = 10;           // BSGS_KERNEL_VARIANT (all bit-identical): per-tile kernels 0 synchronous probes, 1 pipelined probes,
                                 // 2 early / 7 late prefetch, 8 = 7 + LDS-staged probe, 9 = both probes LDS-staged, 6 pair-batched chain,

@@ -449,7 +449,9 @@ static void load_first(const Shared &S, int gpu, bsgs_dev *dev, const std::vecto
 
 static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
 {
-    const size_t batch = 48;                      // one launch; a found key stops the job at the next batch boundary
+    uint32_t tpl = 48;
+    if (bsgs_tiles_per_launch(dev, &tpl) != BSGS_OK || !tpl) tpl = 48;
+    const size_t batch = tpl;                     // one launch (the engine's choice: 48..192 tiles); a found key stops the job at the next batch boundary
     std::vector<Tile> tiles;
     std::vector<uint8_t> centres;
     std::vector<bsgs_hit_ex> hits(65536);
