@@ -63,3 +63,21 @@ def test_two_ranks_gloo(tmp_path):
     assert union == expect
     assert r[0]["steps"] == r[1]["steps"] == len(tiles) * 2 * fx["t"] * fx["b"] * fx["p"]
     assert r[0]["tmax"] == r[1]["tmax"] == 1.5                                          # max over ranks
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks on 127.0.0.1
+    (round 1 parsed --gpus and ignored it); under a launcher (WORLD_SIZE set) it must not spawn again"""
+    env = dict(os.environ, BENCH_PRINT_SPAWN="1")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    cmd = json.loads(res.stdout.strip().splitlines()[-1])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    # already a rank of a launcher: no second spawn (it goes on to need a GPU)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0 and "needs an MI355X" in res.stderr
