@@ -208,6 +208,7 @@ struct Shared {
     std::deque<PendingHit> checker;
     std::atomic<bool> quit{false}, all_done{false};
     std::atomic<uint64_t> steps_done{0}, tiles_done{0};
+    std::atomic<uint64_t> hits_checked{0}, checker_ns{0};   // resolver load: false positives cost CPU (a small BSGS each with an extended table)
     std::atomic<int> gpus_finished{0};
     std::mutex done_mutex;
     std::condition_variable done_cv;
@@ -405,7 +406,11 @@ static void checker_thread(Shared *S)
         }
         if (S->quit.load()) continue;
         Scalar key;
-        if (resolve_hit(*S, hit, key)) {
+        const auto tc0 = std::chrono::steady_clock::now();
+        const bool solved = resolve_hit(*S, hit, key);
+        S->checker_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tc0).count();
+        S->hits_checked++;
+        if (solved) {
             std::lock_guard<std::mutex> lk(S->chk_mutex);
             S->winkey = key; S->found = true;
             S->quit.store(true);
@@ -777,7 +782,7 @@ int main(int argc, char **argv)
             for (bsgs_dev *d : devs) CK(bsgs_set_walk(d, p0, st));      // from here on the host only advances the counter
         }
         S.past_end = false;
-        S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0;
+        S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0; S.hits_checked = 0; S.checker_ns = 0;
         const auto t0 = std::chrono::steady_clock::now();
         Scalar one = hs::fe_from_u64(1), two = hs::fe_from_u64(2);
         Scalar trivial;                                                 // keys 1 and 2 are answered without search (5069-5107)
@@ -823,6 +828,8 @@ int main(int argc, char **argv)
             finditems++;
         } else printf("\nReached end of space\n");
         printf("Job time %.2fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)S.tiles_done.load(), (double)S.steps_done.load());
+        printf("Checker: %llu hits resolved in %.3fs of CPU time (%.2f%% of one core)\n", (unsigned long long)S.hits_checked.load(), S.checker_ns.load() * 1e-9,
+               secs > 0 ? 100.0 * S.checker_ns.load() * 1e-9 / secs : 0.0);
     }
     for (bsgs_dev *d : devs) bsgs_dev_close(d);
     if (S.joblog) fclose(S.joblog);

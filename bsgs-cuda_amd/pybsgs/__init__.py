@@ -126,6 +126,12 @@ def le32(v):
     return int(v).to_bytes(32, "little")
 
 
+def broadcast_tables(devices):
+    """replicas of devices[0]'s giants and table on the other Device objects (device-to-device copies; the same GPU may appear twice)"""
+    arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    _chk(lib().bsgs_broadcast_tables(arr, len(devices)))
+
+
 def device_count():
     n = C.c_int(0)
     _chk(lib().bsgs_dev_count(C.byref(n)))

@@ -273,3 +273,21 @@ def test_config4_true_flags_100_keys(tmp_path):
             json.dump(rec, f)
     except OSError:
         pass
+
+
+def test_config5_style_two_engines_extended_table_120bit_range(tmp_path):
+    """BASELINE config 5 in small: a 120-bit range, the extended table (beyond the reference's file format) built ONCE and
+    replicated to the second engine device-to-device, both driver threads sharing the dispenser.  (Config 5 proper is 8 GPUs
+    with -w 34; one 288 GB GPU holds two engines at -w 33 -htsz 30.)"""
+    import sys
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < 220 * 2**30:
+        pytest.skip("needs ~180 GiB of free HBM")
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    key = (1 << 119) + (300 << 59) + 0x123456789ABCDEF               # 300 tiles of 2^59 keys into the range: both engines get batches
+    out = run(["-t", "256", "-b", "256", "-p", "256", "-w", "33", "-htsz", "30", "-d", "0,0", "-pb", "%064x%064x" % ecpy.mul(key),
+               "-pk", "%x" % (1 << 119), "-pke", "%x" % ((1 << 120) - 1)], tmp_path, timeout=1200)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % key
+    assert out.count("extended table:") == 1 and "replicated to 1 more GPU engine" in out and out.count("job finished") == 2
+    assert "WIDTH RANGE=" in out and "= 2^119" in out
