@@ -291,3 +291,13 @@ def test_config5_style_two_engines_extended_table_120bit_range(tmp_path):
     assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % key
     assert out.count("extended table:") == 1 and "replicated to 1 more GPU engine" in out and out.count("job finished") == 2
     assert "WIDTH RANGE=" in out and "= 2^119" in out
+
+
+def test_host_centres_and_reference_quirk_flags(tmp_path):
+    """-hostcentres (tile centres added on the host and uploaded, the reference's way) and -refquirks (NEGMODP bug reproduced) find
+    the same keys as the defaults"""
+    geo = ["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14", "-pb", PUB_1E9AD, "-pk", "1"]
+    out = run(geo + ["-hostcentres"], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD and "Checker:" in out
+    out = run(geo + ["-refquirks"], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD and "Reference-quirk mode" in out
