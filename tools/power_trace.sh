@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/power_trace.log
 mkdir -p $R/gpurun_out
-python $R/bench.py --no-cpu-baseline --steps 8192 --warmup 32 "$@" > $R/gpurun_out/power_trace_bench.json 2>/dev/null &
+python $R/bench.py --no-cpu-baseline --steps 120 --warmup 5 "$@" > $R/gpurun_out/power_trace_bench.json 2>/dev/null &
 BP=$!
 : > $OUT
 while kill -0 $BP 2>/dev/null; do
