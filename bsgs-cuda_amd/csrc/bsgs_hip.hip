@@ -1104,6 +1104,39 @@ extern "C" int bsgs_bench_random_read(bsgs_dev *d, uint64_t footprint_bytes, uin
     return BSGS_OK;
 }
 
+// diagnostics: where the engine's buffers live (device virtual addresses: lines, chain, giants, csr, centres) and how fast the
+// installed bucket lines THEMSELVES can be read at random (the same cooperative 4-lane pattern as the probe) -- the physical
+// placement of these buffers moves the launch time by up to 10 % (tools/placement_probe.py)
+extern "C" int bsgs_debug_buffers(bsgs_dev *d, uint64_t addr[5], double *lines_random_read_gbps)
+{
+    if (!d || !addr) return fail(BSGS_ERR_ARG, "null");
+    addr[0] = (uint64_t)d->lines; addr[1] = (uint64_t)d->chain; addr[2] = (uint64_t)d->g2; addr[3] = (uint64_t)d->csr; addr[4] = (uint64_t)d->cen_dev;
+    if (lines_random_read_gbps) {
+        *lines_random_read_gbps = 0;
+        if (d->lines && d->layout == BSGS_TABLE_LINES64) {
+            HIPCHK(hipSetDevice(d->id));
+            uint64_t n = 1;
+            while (n * 2 <= d->ht_items) n *= 2;
+            u32 *out = nullptr;
+            HIPCHK(hipMalloc(&out, 64));
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            const int blocks = 256 * 8, iters = 128;
+            for (int rep = 0; rep < 2; rep++) {
+                HIPCHK(hipEventRecord(e0, d->stream));
+                hipLaunchKernelGGL(mb_gups_kernel<4>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)d->lines, n - 1, iters, out, 91ull + rep);
+                HIPCHK(hipEventRecord(e1, d->stream));
+                HIPCHK(hipStreamSynchronize(d->stream));
+            }
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            *lines_random_read_gbps = (double)blocks * 256 * iters * 8 / 4 * 64 / (ms * 1e-3) / 1e9;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+        }
+    }
+    return BSGS_OK;
+}
+
 __global__ void __launch_bounds__(256) mb_modmul_kernel(fe *out, int iters, u32 seed)
 {
     const u32 t = threadIdx.x + blockIdx.x * blockDim.x;

@@ -24,7 +24,7 @@ NATIVE_SYMBOLS = [
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
-    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -107,6 +107,7 @@ def lib():
             "bsgs_engine_geometry": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
             "bsgs_run_digest": [vp, u8p, C.c_uint32, vp, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32)],
             "bsgs_selftest_lo64": [vp, u8p, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)],
+            "bsgs_debug_buffers": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -345,6 +346,12 @@ class Device:
         g, r = C.c_double(), C.c_double()
         _chk(self.L.bsgs_bench_random_read(self.h, footprint_bytes, granule, C.byref(g), C.byref(r)))
         return g.value, r.value
+
+    def debug_buffers(self, measure=True):
+        a = (C.c_uint64 * 5)()
+        g = C.c_double()
+        _chk(self.L.bsgs_debug_buffers(self.h, a, C.byref(g) if measure else None))
+        return [int(x) for x in a], g.value
 
     def bench_modmul(self):
         g = C.c_double()

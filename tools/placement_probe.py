@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Does the physical placement of the engine's buffers change the launch time?  One process, the default workload: time launches, then
+re-create one buffer at a time (bucket lines / chain scratch / giants), optionally behind a dummy allocation that shifts the placement,
+and time again.  (Run-to-run the bench alternates between ~164 and ~177 ms per 192-tile launch on one box: profiles/r02d_repeat.log.)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+import torch  # noqa: E402
+import pybsgs  # noqa: E402
+from pybsgs import ecpy  # noqa: E402
+
+t, b, p, wexp, htsz = 256, 256, 256, 30, 28
+w, items = 1 << wexp, 1 << htsz
+dev = pybsgs.Device(0)
+img = torch.empty(items + 1 + w, dtype=torch.int32, device="cuda:0")
+dev.build_baby_tables_device(w, htsz, img.data_ptr())
+A = ecpy.addpubg(w)
+_, D = ecpy.tile_stride(t, b, p, w)
+p0 = ecpy.mul(0x5EED5EED)
+
+
+def measure(tag, n=4):
+    tpl = dev.tiles_per_launch()
+    dev.set_walk(p0, D)
+    dev.enqueue_walk(0, tpl)
+    dev.collect()
+    for k in range(n):
+        dev.enqueue_walk((k + 1) * tpl, tpl)
+    _, _, ms = dev.collect()
+    addr, gbps = dev.debug_buffers()
+    print("%-44s %7.2f ms per %d-tile launch = %.2f G/s   lines@%x chain@%x g2@%x  lines random read %.0f GB/s" % (
+        tag, ms / n, tpl, tpl * 2**25 / (ms / n * 1e-3) / 1e9, addr[0], addr[1], addr[2], gbps), flush=True)
+
+
+dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
+dev.generate_g2(A[0], A[1], t, b, p)
+measure("initial")
+measure("again")
+dummies = []
+for rnd in range(4):
+    dev.upload_htgpu_device(img.data_ptr(), items, w, 0)       # frees and re-creates the 16 GiB of bucket lines
+    measure("lines re-created (%d)" % rnd)
+    dummies.append(torch.empty((3 + 2 * rnd) << 28, dtype=torch.int32, device="cuda:0"))   # 3, 5, 7, 9 GiB: shifts what comes next
+    dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
+    measure("lines re-created behind a %d GiB dummy" % (3 + 2 * rnd))
+    dev.generate_g2(A[0], A[1], t, b, p)                        # frees giants AND the chain scratch; both re-created
+    measure("giants + chain re-created")
+dev.close()
