@@ -5,6 +5,7 @@
 #include "host_secp.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,29 @@ extern "C" const char *bsgs_last_error(void) { return g_err.c_str(); }
 extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
 
 static void release_pending(bsgs_dev *d);
+
+static std::atomic<uint64_t> g_alloc_contiguous{0}, g_alloc_plain{0};
+// bytes of big buffers this process obtained as physically contiguous memory / as ordinary pages (cumulative)
+extern "C" int bsgs_alloc_stats(uint64_t *contiguous_bytes, uint64_t *plain_bytes)
+{
+    if (contiguous_bytes) *contiguous_bytes = g_alloc_contiguous.load();
+    if (plain_bytes) *plain_bytes = g_alloc_plain.load();
+    return BSGS_OK;
+}
+hipError_t bsgs_big_malloc(void **p, size_t bytes)
+{
+    // BSGS_CONTIGUOUS=1 asks for physically contiguous VRAM first (large page-table fragments).  It was tried as an explanation
+    // of the run-to-run levels of the tile kernel (34.6 / 36.3 / 37.4 / 39.4 G on one box with one binary) and does not remove
+    // them -- 14 runs with, 14 without: the same levels, the same mean (profiles/r02e_contiguous_allocation.log) -- so it stays off.
+    static const int mode = getenv("BSGS_CONTIGUOUS") ? atoi(getenv("BSGS_CONTIGUOUS")) : 0;
+    if (mode == 1 && bytes >= (64u << 20)) {
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) { g_alloc_contiguous += bytes; return hipSuccess; }
+        (void)hipGetLastError();                                   // refused (fragmented / too large): ordinary pages
+    }
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && bytes >= (64u << 20)) g_alloc_plain += bytes;
+    return e;
+}
 static size_t hitbuf_bytes(const bsgs_dev *d) { return 64 + (size_t)d->max_hits * 16; }
 
 extern "C" int bsgs_dev_count(int *n)
@@ -193,7 +217,7 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     else while ((uint64_t)p * m * 2 <= 1024 && T % (2ull * m) == 0 && T / (2ull * m) >= 2048 && (T / (2ull * m)) % 256 == 0) m *= 2;
     if (T % m) m = 1;
     d->Ti = (uint32_t)(T / m); d->pi = p * m;
-    HIPCHK(hipMalloc(&d->g2, maxnonce * 64));
+    HIPCHK(bsgs_big_malloc(&d->g2, maxnonce * 64));
     return BSGS_OK;
 }
 
@@ -202,11 +226,15 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
 static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
 {
     const bool halfchain = !full && (d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);   // = the dispatch of giant_pair2_kernel
-    const uint64_t per_stream = d->maxnonce * (halfchain ? 16 : 32) * tiles;
+    // the tiles' scratch areas are 2^28 bytes apart at the usual geometry; tiles of a launch touch the same offsets at about the
+    // same time, so a pad breaks the power-of-two stride between them (BSGS_CHAIN_PAD bytes, pair-batched kernel only)
+    static const uint64_t pad_env = getenv("BSGS_CHAIN_PAD") ? strtoull(getenv("BSGS_CHAIN_PAD"), nullptr, 10) : 0;
+    d->chain_pad = halfchain ? (uint32_t)(pad_env / 16) : 0;
+    const uint64_t per_stream = (d->maxnonce * (halfchain ? 16 : 32) + (uint64_t)d->chain_pad * 16) * tiles;
     const uint64_t bytes = per_stream * (d->nstreams == 2 ? 2 : 1);                 // one scratch per stream
     if (d->chain && d->chain_bytes >= bytes) { d->chain_stride = per_stream / 16; return BSGS_OK; }
     if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
-    if (hipMalloc(&d->chain, bytes) != hipSuccess) {
+    if (bsgs_big_malloc(&d->chain, bytes) != hipSuccess) {
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
         d->chain = nullptr;
@@ -318,7 +346,7 @@ static int build_lines(bsgs_dev *d, uint32_t layout, bool with_list)
 {
     const int lplog = layout == BSGS_TABLE_LINES128 ? 3 : 2;
     d->lines_bytes = d->ht_items * (64ull << (lplog - 2));
-    HIPCHK(hipMalloc(&d->lines, d->lines_bytes));
+    HIPCHK(bsgs_big_malloc(&d->lines, d->lines_bytes));
     unsigned long long *cnt = nullptr, h[2] = {0, 0};
     HIPCHK(hipMalloc(&cnt, 16));
     const int blocks = (int)std::min<uint64_t>((d->ht_items + 255) / 256, 1u << 20);
@@ -418,7 +446,7 @@ extern "C" int bsgs_upload_htgpu(bsgs_dev *d, const void *image, uint64_t ht_ite
     HIPCHK(hipSetDevice(d->id));
     free_table(d);
     const uint64_t bytes = 4 * (ht_items + 1) + 4 * w;
-    HIPCHK(hipMalloc(&d->csr, bytes));
+    HIPCHK(bsgs_big_malloc(&d->csr, bytes));
     d->csr_owned = true;
     HIPCHK(hipMemcpy(d->csr, image, bytes, hipMemcpyHostToDevice));
     return finish_table(d, ht_items, w, layout);
@@ -475,6 +503,7 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     A.debug_flags = d->debug_flags; A.pad0 = 0;
     A.centres_dev = centres_dev; A.pool = nullptr; A.pool_cap = 0; A.pool_stride = 0;
     A.digest = d->digest ? d->digest + (uint64_t)seq * d->Ti * 2 : nullptr;
+    A.chain_pad = d->chain_pad; A.pad1 = 0;
     const unsigned bs = d->block_size;
     if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) {
         // the reference's own P - G arithmetic for the listed giants; bsgs_collect drops the hot loop's records for them
@@ -598,7 +627,7 @@ static int ensure_pool(bsgs_dev *d)
     }
     if (d->chain && d->chain_bytes >= bytes) return BSGS_OK;
     if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
-    if (hipMalloc(&d->chain, bytes) != hipSuccess) { d->chain = nullptr; return fail(BSGS_ERR_NOMEM, "pooled chain scratch: %.1f GiB", bytes / 1073741824.0); }
+    if (bsgs_big_malloc(&d->chain, bytes) != hipSuccess) { d->chain = nullptr; return fail(BSGS_ERR_NOMEM, "pooled chain scratch: %.1f GiB", bytes / 1073741824.0); }
     d->chain_bytes = bytes;
     return BSGS_OK;
 }
@@ -909,6 +938,38 @@ extern "C" int bsgs_run_digest(bsgs_dev *d, const uint8_t *centres, uint32_t nti
     return rc;
 }
 
+// diagnostics: one walk launch of `ntiles` tiles with every block recording its XCD; out[2x] = time (100 MHz ticks, relative to the
+// earliest XCD's last block) at which XCD x finished its last block, out[2x+1] = blocks XCD x ran.  The block -> XCD assignment is
+// static (blockIdx % 8): an XCD that runs slower than the others (per-XCD clocks under the power cap) sets the launch time.
+static __global__ void wallclock_kernel(unsigned long long *out) { out[0] = wall_clock64(); }
+extern "C" int bsgs_debug_xcd_profile(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, uint64_t out[16], float *launch_ms)
+{
+    if (!d || !out) return fail(BSGS_ERR_ARG, "null");
+    if (!d->walk_set) return fail(BSGS_ERR_STATE, "bsgs_set_walk first");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued");
+    if ((d->pi & 1u) || !lines_layout(d)) return fail(BSGS_ERR_STATE, "default kernel only");
+    HIPCHK(hipSetDevice(d->id));
+    HIPCHK(hipMalloc(&d->digest, 17 * 8));
+    hipError_t e = hipMemsetAsync(d->digest, 0, 17 * 8, d->stream);
+    hipLaunchKernelGGL(wallclock_kernel, dim3(1), dim3(1), 0, d->stream, (unsigned long long *)d->digest + 16);
+    const unsigned saved_flags = d->debug_flags;
+    const int saved_variant = d->variant;
+    const uint32_t saved_tpl = d->tiles_per_launch;
+    d->debug_flags = 16u; d->variant = 10; d->phase_probe = true; d->tiles_per_launch = ntiles;
+    // launch_tiles offsets the digest pointer by seq * Ti * 2: one launch, seq = 0
+    int rc = e == hipSuccess ? bsgs_run_walk(d, first_tile, ntiles, nullptr, 0, nullptr, launch_ms) : fail(BSGS_ERR_HIP, "memset");
+    d->debug_flags = saved_flags; d->variant = saved_variant; d->phase_probe = false; d->tiles_per_launch = saved_tpl;
+    uint64_t h[17];
+    if (rc == BSGS_OK || rc == BSGS_ERR_OVERFLOW) {
+        rc = BSGS_OK;
+        if (hipMemcpy(h, d->digest, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(BSGS_ERR_HIP, "read-back");
+        else for (int x = 0; x < 8; x++) { out[2 * x] = h[2 * x] ? h[2 * x] - h[16] : 0; out[2 * x + 1] = h[2 * x + 1]; }
+    }
+    (void)hipFree(d->digest);
+    d->digest = nullptr;
+    return rc;
+}
+
 // ---- replicas for several GPUs of one process: the reference uploads G2 and htGPU to every GPU over PCIe (1_9_7File.pb:2337,
 // 2350, 4769-4843).  Here devs[0] holds the giants and the table (file-backed or GPU-built) and every other device gets its
 // replica by a direct device-to-device copy, all destinations at once, each on its own stream: on the fully connected xGMI mesh
@@ -940,12 +1001,12 @@ extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
         d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->layout = s->layout; d->lines_bytes = s->lines_bytes;
         if (s->csr) {
             const uint64_t bytes = 4 * (s->ht_items + 1) + 4 * s->w;
-            HIPCHK(hipMalloc(&d->csr, bytes));
+            HIPCHK(bsgs_big_malloc(&d->csr, bytes));
             d->csr_owned = true;
             HIPCHK(hipMemcpyPeerAsync(d->csr, d->id, s->csr, s->id, bytes, d->stream));
         }
         if (s->lines) {
-            HIPCHK(hipMalloc(&d->lines, s->lines_bytes));
+            HIPCHK(bsgs_big_malloc(&d->lines, s->lines_bytes));
             d->lines_owned = true;
             HIPCHK(hipMemcpyPeerAsync(d->lines, d->id, s->lines, s->id, s->lines_bytes, d->stream));
         }
@@ -1134,6 +1195,35 @@ extern "C" int bsgs_debug_buffers(bsgs_dev *d, uint64_t addr[5], double *lines_r
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
         }
     }
+    return BSGS_OK;
+}
+
+// diagnostics: give ONE of the engine's buffers a new allocation with the same contents (0 = bucket lines, 1 = chain scratch,
+// 2 = giants), optionally after a `spacer_bytes` allocation that is released again (so the new one lands elsewhere)
+extern "C" int bsgs_debug_realloc(bsgs_dev *d, int which, uint64_t spacer_bytes)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued");
+    HIPCHK(hipSetDevice(d->id));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    void *spacer = nullptr;
+    if (spacer_bytes) HIPCHK(hipMalloc(&spacer, spacer_bytes));
+    hipError_t e = hipSuccess;
+    if (which == 0 && d->lines && d->lines_owned) {
+        void *n = nullptr;
+        e = bsgs_big_malloc(&n, d->lines_bytes);
+        if (e == hipSuccess) e = hipMemcpy(n, d->lines, d->lines_bytes, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) { (void)hipFree(d->lines); d->lines = (u32x4 *)n; }
+    } else if (which == 1 && d->chain) {
+        (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0;                 // scratch: the next enqueue allocates it again
+    } else if (which == 2 && d->g2) {
+        void *n = nullptr;
+        e = hipMalloc(&n, d->maxnonce * 64);
+        if (e == hipSuccess) e = hipMemcpy(n, d->g2, d->maxnonce * 64, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess) { (void)hipFree(d->g2); d->g2 = (u32x4 *)n; }
+    }
+    if (spacer) (void)hipFree(spacer);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "debug_realloc: %s", hipGetErrorString(e));
     return BSGS_OK;
 }
 

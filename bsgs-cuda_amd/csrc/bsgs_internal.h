@@ -28,6 +28,7 @@ struct bsgs_dev {
     uint64_t T = 0, maxnonce = 0;
     uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
     uint64_t chain_bytes = 0, chain_stride = 0;   // size of the chain scratch; u32x4 elements per stream
+    uint32_t chain_pad = 0;                       // extra u32x4 elements between the scratch areas of consecutive tiles
     u32 *pool = nullptr;                   // pooled launches: per-XCD rings of free chain slots
     uint32_t pool_cap = 0, pool_stride = 0, nxcc = 0;
     u32x4 *schain = nullptr;               // streamed kernel: one scratch slot per resident block
@@ -73,6 +74,11 @@ struct bsgs_dev {
     u64 *digest = nullptr;                 // bsgs_run_digest: [tile][Ti][2]
     uint64_t digest_bytes = 0;
 };
+
+// the big, long-lived device buffers (bucket lines, chain scratch, giants).  BSGS_CONTIGUOUS=1: ask for physically contiguous
+// memory first (hipDeviceMallocContiguous), plain hipMalloc when that is refused.
+hipError_t bsgs_big_malloc(void **p, size_t bytes);
+template <typename T> static inline hipError_t bsgs_big_malloc(T **p, size_t bytes) { return bsgs_big_malloc((void **)p, bytes); }
 
 // shared between the translation units of the library
 void bsgs_free_table(bsgs_dev *d);

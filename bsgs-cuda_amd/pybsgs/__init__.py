@@ -24,7 +24,7 @@ NATIVE_SYMBOLS = [
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
-    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_debug_xcd_profile",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -108,6 +108,8 @@ def lib():
             "bsgs_run_digest": [vp, u8p, C.c_uint32, vp, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32)],
             "bsgs_selftest_lo64": [vp, u8p, u8p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)],
             "bsgs_debug_buffers": [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
+            "bsgs_debug_realloc": [vp, C.c_int, C.c_uint64],
+            "bsgs_debug_xcd_profile": [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_float)],
         }
         for name, args in sig.items():
             fn = getattr(L, name)
@@ -131,6 +133,14 @@ def broadcast_tables(devices):
     """replicas of devices[0]'s giants and table on the other Device objects (device-to-device copies; the same GPU may appear twice)"""
     arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
     _chk(lib().bsgs_broadcast_tables(arr, len(devices)))
+
+
+def alloc_stats():
+    """(bytes of big buffers obtained physically contiguous, bytes obtained as ordinary pages) by this process so far"""
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().bsgs_alloc_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _chk(lib().bsgs_alloc_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def device_count():
@@ -352,6 +362,16 @@ class Device:
         g = C.c_double()
         _chk(self.L.bsgs_debug_buffers(self.h, a, C.byref(g) if measure else None))
         return [int(x) for x in a], g.value
+
+    def xcd_profile(self, first, ntiles):
+        """([(ms until XCD x finished its last block, blocks it ran)] x 8, launch ms)"""
+        out = (C.c_uint64 * 16)()
+        ms = C.c_float()
+        _chk(self.L.bsgs_debug_xcd_profile(self.h, first, ntiles, out, C.byref(ms)))
+        return [(out[2 * x] / 1e5, int(out[2 * x + 1])) for x in range(8)], ms.value
+
+    def debug_realloc(self, which, spacer_bytes=0):
+        _chk(self.L.bsgs_debug_realloc(self.h, which, spacer_bytes))
 
     def bench_modmul(self):
         g = C.c_double()

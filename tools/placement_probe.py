@@ -39,13 +39,25 @@ dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
 dev.generate_g2(A[0], A[1], t, b, p)
 measure("initial")
 measure("again")
-dummies = []
-for rnd in range(4):
-    dev.upload_htgpu_device(img.data_ptr(), items, w, 0)       # frees and re-creates the 16 GiB of bucket lines
-    measure("lines re-created (%d)" % rnd)
-    dummies.append(torch.empty((3 + 2 * rnd) << 28, dtype=torch.int32, device="cuda:0"))   # 3, 5, 7, 9 GiB: shifts what comes next
-    dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
-    measure("lines re-created behind a %d GiB dummy" % (3 + 2 * rnd))
-    dev.generate_g2(A[0], A[1], t, b, p)                        # frees giants AND the chain scratch; both re-created
-    measure("giants + chain re-created")
+if len(sys.argv) > 1 and sys.argv[1] == "xcd":
+    measure("production launches")
+    for k in range(4):
+        prof, ms = dev.xcd_profile(1000 * (k + 1), dev.tiles_per_launch())
+        ends = [e for e, _ in prof]
+        print("launch %.2f ms; per XCD: last block ends at %s ms (spread %.1f ms), blocks %s" % (
+            ms, " ".join("%.1f" % e for e in ends), max(ends) - min(ends), [n for _, n in prof]), flush=True)
+    dev.close()
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "idle":
+    # does an idle gap move the operating point?
+    for gap in (0.0, 0.05, 0.2, 0.5, 1.0, 2.0, 0.0, 0.5, 0.5, 0.5, 2.0, 2.0, 5.0, 0.0):
+        time.sleep(gap)
+        measure("after %.2f s idle" % gap)
+    dev.close()
+    sys.exit(0)
+names = {0: "bucket lines (16 GiB, random access)", 1: "chain scratch (48 GiB, streamed)", 2: "giants (1 GiB, through L2)"}
+for which in (1, 1, 1, 2, 2, 2, 0, 0, 0, 1, 2, 0):
+    for spacer in (0, 3 << 30):
+        dev.debug_realloc(which, spacer)
+        measure("moved: %s%s" % (names[which][:14], " (+3 GiB spacer)" if spacer else ""))
 dev.close()
