@@ -39,6 +39,17 @@ dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
 dev.generate_g2(A[0], A[1], t, b, p)
 measure("initial")
 measure("again")
+if len(sys.argv) > 1 and sys.argv[1] == "reroll":
+    # close the engine, open a new one, load everything again: does the level change inside one process?
+    measure("first engine")
+    for k in range(7):
+        dev.close()
+        dev = pybsgs.Device(0)
+        dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
+        dev.generate_g2(A[0], A[1], t, b, p)
+        measure("engine %d (everything re-created)" % (k + 2))
+    dev.close()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "xcd":
     measure("production launches")
     for k in range(4):
