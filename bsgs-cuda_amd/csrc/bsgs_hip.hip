@@ -230,7 +230,9 @@ static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
     // same time, so a pad breaks the power-of-two stride between them (BSGS_CHAIN_PAD bytes, pair-batched kernel only)
     static const uint64_t pad_env = getenv("BSGS_CHAIN_PAD") ? strtoull(getenv("BSGS_CHAIN_PAD"), nullptr, 10) : 0;
     d->chain_pad = halfchain ? (uint32_t)(pad_env / 16) : 0;
-    const uint64_t per_stream = (d->maxnonce * (halfchain ? 16 : 32) + (uint64_t)d->chain_pad * 16) * tiles;
+    // the pair-batched kernel's scratch is [tile][block][pair][2][block size]: whole blocks (the tail block is padded)
+    const uint64_t threads_padded = ((uint64_t)d->Ti + d->block_size - 1) / d->block_size * d->block_size;
+    const uint64_t per_stream = ((halfchain ? threads_padded * d->pi * 16 : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16) * tiles;
     const uint64_t bytes = per_stream * (d->nstreams == 2 ? 2 : 1);                 // one scratch per stream
     if (d->chain && d->chain_bytes >= bytes) { d->chain_stride = per_stream / 16; return BSGS_OK; }
     if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
@@ -1216,6 +1218,18 @@ extern "C" int bsgs_debug_realloc(bsgs_dev *d, int which, uint64_t spacer_bytes)
         if (e == hipSuccess) { (void)hipFree(d->lines); d->lines = (u32x4 *)n; }
     } else if (which == 1 && d->chain) {
         (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0;                 // scratch: the next enqueue allocates it again
+    } else if (which == 3) {                                     // a new HIP stream (= possibly another hardware queue)
+        hipStream_t ns = nullptr;
+        e = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);
+        if (e == hipSuccess) { (void)hipStreamDestroy(d->stream); d->stream = ns; }
+    } else if (which == 4 && d->hitbuf) {                        // hit buffer + centres
+        u32 *nh = nullptr;
+        e = hipMalloc(&nh, hitbuf_bytes(d));
+        if (e == hipSuccess) e = hipMemset(nh, 0, 64);
+        if (e == hipSuccess) { (void)hipFree(d->hitbuf); d->hitbuf = nh; }
+        if (d->cen_dev) { (void)hipFree(d->cen_dev); d->cen_dev = nullptr; }
+        if (d->cen_pin) { (void)hipHostFree(d->cen_pin); d->cen_pin = nullptr; }
+        d->cen_cap = 0;
     } else if (which == 2 && d->g2) {
         void *n = nullptr;
         e = hipMalloc(&n, d->maxnonce * 64);

@@ -39,6 +39,27 @@ dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
 dev.generate_g2(A[0], A[1], t, b, p)
 measure("initial")
 measure("again")
+if len(sys.argv) > 1 and sys.argv[1] == "each":
+    measure("first"); measure("second"); measure("third")
+    for which, name in ((1, "chain"), (0, "lines"), (2, "giants"), (1, "chain")):
+        for k in range(8):
+            dev.debug_realloc(which, (k % 3) << 30)
+            measure("%s moved %d" % (name, k + 1))
+    dev.close()
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "stream":
+    measure("first")
+    for k in range(6):
+        dev.debug_realloc(3)
+        measure("new stream %d" % (k + 1))
+    for k in range(4):
+        dev.debug_realloc(4)
+        measure("new hit buffer + centres %d" % (k + 1))
+    for k in range(4):
+        dev.debug_realloc(1); dev.debug_realloc(2); dev.debug_realloc(0)
+        measure("chain + giants + lines moved %d" % (k + 1))
+    dev.close()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "reroll":
     # close the engine, open a new one, load everything again: does the level change inside one process?
     measure("first engine")
