@@ -39,6 +39,34 @@ dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
 dev.generate_g2(A[0], A[1], t, b, p)
 measure("initial")
 measure("again")
+if len(sys.argv) > 1 and sys.argv[1] == "stable":
+    # is the level of a chain-scratch placement stable right after the allocation churn that produced it?
+    measure("as started")
+    for k in range(6):
+        dev.debug_realloc(1, (k % 3) << 30)
+        for rep in range(4):
+            measure("chain placement %d, measurement %d" % (k + 1, rep + 1))
+    dev.close()
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "kick":
+    # is the level an operating point of the power manager that a burst of extra load can move?
+    import threading
+    measure("as started"); measure("again")
+    kicker = pybsgs.Device(0)
+    for rnd in range(3):
+        stop = threading.Event()
+
+        def burn():
+            while not stop.is_set():
+                kicker.bench_modmul()                      # pure multiply-add load on another stream (~50 ms per call)
+        th = threading.Thread(target=burn)
+        th.start()
+        measure("WITH a concurrent arithmetic load (round %d)" % (rnd + 1))
+        stop.set(); th.join()
+        measure("after the load"); measure("after the load, again")
+    kicker.close()
+    dev.close()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "each":
     measure("first"); measure("second"); measure("third")
     for which, name in ((1, "chain"), (0, "lines"), (2, "giants"), (1, "chain")):
