@@ -44,7 +44,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "stable":
     measure("as started")
     for k in range(6):
         dev.debug_realloc(1, (k % 3) << 30)
-        for rep in range(4):
+        for rep in range(int(os.environ.get("PROBE_REPS", "4"))):
             measure("chain placement %d, measurement %d" % (k + 1, rep + 1))
     dev.close()
     sys.exit(0)
