@@ -801,6 +801,104 @@ extern "C" int bsgs_run_walk(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, 
     return bsgs_collect(d, hits, max_hits, nhits, kernel_ms);
 }
 
+// Start-up tuning of WHERE the chain scratch and the bucket lines lie.  The launch time of the tile kernel depends on the physical
+// memory the driver happened to hand out for these two buffers (159 ... 186 ms for the same 192 tiles); every allocation
+// re-draws it and the level then persists for the life of the allocation (profiles/r02g_tuned_placement_persists.log).  So: time
+// launches of walk tiles on up to `candidates` allocations of the scratch -- all held at once, so that every one is different memory --
+// keep the fastest, free the rest; then the same for the bucket lines (device-to-device copies).  Freeing tens of GiB slows the GPU
+// down for a second or two (the driver wipes released memory), so the call ends by running launches until the chosen time is back.
+// Needs the walk, the giants and the table; the tiles' hits are discarded; a buffer is left alone (not an error) when the free memory
+// does not hold a second copy of it.  ms_out[0..candidates) = launch times on the scratch candidates, ms_out[candidates..2*candidates) on
+// the line candidates (0 = not tried); chosen[0], chosen[1] = indices kept.
+extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_out, uint32_t chosen[2], float *final_ms)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (!d->walk_set) return fail(BSGS_ERR_STATE, "bsgs_set_walk first");
+    if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    if (candidates == 0 || candidates > 16) return fail(BSGS_ERR_ARG, "1..16 candidates");
+    HIPCHK(hipSetDevice(d->id));
+    const uint32_t tpl = auto_tiles_per_launch(d);
+    auto launch = [&](float *ms) -> int {
+        int rc = bsgs_enqueue_walk(d, 0, tpl);
+        if (rc) return rc;
+        uint32_t n = 0;
+        rc = bsgs_collect(d, nullptr, 0, &n, ms);
+        return rc == BSGS_ERR_OVERFLOW ? BSGS_OK : rc;
+    };
+    auto timed = [&](float *ms) -> int {                   // one warm launch, then two timed ones
+        float t[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; k++) { int rc = launch(&t[k]); if (rc) return rc; }
+        *ms = (t[1] + t[2]) / 2;
+        return BSGS_OK;
+    };
+    auto room_for = [&](uint64_t bytes) { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= bytes + (8ull << 30); };
+    if (ms_out) for (uint32_t k = 0; k < 2 * candidates; k++) ms_out[k] = 0.f;
+    float best_ms = 0.f;
+    int rc = BSGS_OK;
+    // ---- chain scratch
+    {
+        std::vector<u32x4 *> held;
+        std::vector<float> ms;
+        float t = 0.f;
+        if ((rc = timed(&t))) return rc;                   // allocates the scratch if this is the first launch
+        held.push_back(d->chain); ms.push_back(t);
+        const uint64_t bytes = d->chain_bytes;
+        while (held.size() < candidates && room_for(bytes)) {
+            void *fresh = nullptr;
+            if (bsgs_big_malloc(&fresh, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            d->chain = (u32x4 *)fresh;
+            held.push_back((u32x4 *)fresh);
+            if ((rc = timed(&t))) break;
+            ms.push_back(t);
+        }
+        size_t best = 0;
+        for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;      // a new placement has to win by 0.5 %
+        (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->stream2);
+        for (size_t k = 0; k < held.size(); k++) if (k != best) (void)hipFree(held[k]);
+        d->chain = held[best];
+        if (rc) return rc;
+        if (ms_out) for (size_t k = 0; k < ms.size(); k++) ms_out[k] = ms[k];
+        if (chosen) chosen[0] = (uint32_t)best;
+        best_ms = ms[best];
+    }
+    // ---- bucket lines (only the engine's own copy can move)
+    if (chosen) chosen[1] = 0;
+    if (lines_layout(d) && d->lines && d->lines_owned) {
+        std::vector<u32x4 *> held;
+        std::vector<float> ms;
+        held.push_back(d->lines); ms.push_back(best_ms);
+        const uint64_t bytes = d->lines_bytes;
+        float t = 0.f;
+        while (held.size() < candidates && room_for(bytes)) {
+            void *fresh = nullptr;
+            if (bsgs_big_malloc(&fresh, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            held.push_back((u32x4 *)fresh);
+            if (hipMemcpy(fresh, held[0], bytes, hipMemcpyDeviceToDevice) != hipSuccess) { rc = fail(BSGS_ERR_HIP, "copying the bucket lines"); break; }
+            d->lines = (u32x4 *)fresh;
+            if ((rc = timed(&t))) break;
+            ms.push_back(t);
+        }
+        size_t best = 0;
+        for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;
+        (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->stream2);
+        for (size_t k = 0; k < held.size(); k++) if (k != best) (void)hipFree(held[k]);
+        d->lines = held[best];
+        if (rc) return rc;
+        if (ms_out) for (size_t k = 0; k < ms.size(); k++) ms_out[candidates + k] = ms[k];
+        if (chosen) chosen[1] = (uint32_t)best;
+        best_ms = ms[best];
+    }
+    // ---- let the driver finish wiping what was freed
+    float t = 0.f;
+    for (int k = 0, calm = 0; k < 48 && calm < 4; k++) {   // four launches in a row at the chosen time (the wipe comes in bursts), 8 s at most
+        if ((rc = launch(&t))) return rc;
+        calm = t <= best_ms * 1.01f ? calm + 1 : 0;
+    }
+    if (final_ms) *final_ms = t;
+    return BSGS_OK;
+}
+
 // the centres bsgs_enqueue_walk would use, for callers that need a tile's centre on the host (resolving a hit) and for tests
 extern "C" int bsgs_walk_centres(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, uint8_t *centres_out)
 {

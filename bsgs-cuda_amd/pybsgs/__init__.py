@@ -24,7 +24,7 @@ NATIVE_SYMBOLS = [
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
-    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_debug_xcd_profile",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_debug_xcd_profile",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -369,6 +369,17 @@ class Device:
         ms = C.c_float()
         _chk(self.L.bsgs_debug_xcd_profile(self.h, first, ntiles, out, C.byref(ms)))
         return [(out[2 * x] / 1e5, int(out[2 * x + 1])) for x in range(8)], ms.value
+
+    def tune_placement(self, candidates=3):
+        """start-up tuning of where chain scratch and bucket lines lie (bsgs_tune_placement):
+        {"chain_ms": [...], "lines_ms": [...], "kept": (i, j), "final_ms": ms}"""
+        ms = (C.c_float * (2 * candidates))()
+        chosen = (C.c_uint32 * 2)()
+        fin = C.c_float()
+        self.L.bsgs_tune_placement.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        _chk(self.L.bsgs_tune_placement(self.h, candidates, ms, chosen, C.byref(fin)))
+        return {"chain_ms": [round(ms[k], 2) for k in range(candidates) if ms[k] > 0], "lines_ms": [round(ms[candidates + k], 2) for k in range(candidates) if ms[candidates + k] > 0],
+                "kept": (int(chosen[0]), int(chosen[1])), "final_ms": round(fin.value, 2)}
 
     def debug_realloc(self, which, spacer_bytes=0):
         _chk(self.L.bsgs_debug_realloc(self.h, which, spacer_bytes))

@@ -39,6 +39,17 @@ dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
 dev.generate_g2(A[0], A[1], t, b, p)
 measure("initial")
 measure("again")
+if len(sys.argv) > 1 and sys.argv[1] == "tune":
+    # does the placement bsgs_tune_placement picks keep its level afterwards?
+    measure("as started"); measure("again")
+    for rnd in range(2):
+        t0 = time.time()
+        r = dev.tune_placement(int(os.environ.get("PROBE_CANDIDATES", "3")))
+        print("tune_placement:", r, "%.1f s" % (time.time() - t0), flush=True)
+        for rep in range(5):
+            measure("after tuning, measurement %d" % (rep + 1))
+    dev.close()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "stable":
     # is the level of a chain-scratch placement stable right after the allocation churn that produced it?
     measure("as started")
