@@ -52,6 +52,32 @@ def test_key_1e9ad(tmp_path):
     assert "KEY[1]" in out
 
 
+@pytest.mark.parametrize("geo", [["-t", "64", "-b", "8", "-p", "16", "-w", "100003", "-htsz", "14"],      # -w above 36: a decimal count (1_9_7File.pb:1009-1022)
+                                 ["-t", "96", "-b", "5", "-p", "6", "-w", "77777", "-htsz", "13"],        # 480 engine threads: a ragged last wave
+                                 ["-t", "32", "-b", "3", "-p", "10", "-w", "65537", "-htsz", "16"]])      # 96 engine threads, one entry per bucket
+def test_ragged_geometry_and_decimal_w(tmp_path, geo):
+    """baby-step counts that are not powers of two, thread counts that are not multiples of a wave: the tables are built, saved,
+    found again on the second run, and the key is recovered from both ends of the range; an odd -p is refused like the reference
+    refuses it (1_9_7File.pb:4616-4618)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
+    from pybsgs import ecpy
+    w = int(geo[7])
+    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1"], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
+    assert any(("_%d_" % w) in f and f.endswith("_htGPUv0.BIN") for f in os.listdir(tmp_path))
+    key = 0x7000000000 + 12345
+    out = run(geo + ["-pb", "%064x%064x" % ecpy.mul(key), "-pk", "7000000000", "-pke", "7100000000"], tmp_path)
+    assert "Both HT files exist" in out
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % key
+    key = 0x7100000000 - 3                                                   # the far end of the range
+    run(geo + ["-pb", "%064x%064x" % ecpy.mul(key), "-pk", "7000000000", "-pke", "7100000000"], tmp_path)
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % key
+    odd = list(geo); odd[5] = "7"
+    res = subprocess.run([EXE, "-dir", str(tmp_path)] + odd + ["-pb", PUB_1E9AD, "-pk", "1"], capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "-p must be even" in res.stderr
+
+
 def test_key_65bit_default_range_and_puzzle64(tmp_path):
     """the reference's default job (1_9_7File.pb:191, 197, 210) and the puzzle-64 vector (200-203)"""
     geo = ["-t", "256", "-b", "64", "-p", "256", "-w", "26", "-htsz", "24"]
