@@ -890,10 +890,12 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
         best_ms = ms[best];
     }
     // ---- let the driver finish wiping what was freed
+    // The wipe of the freed buffers comes in bursts of ~0.5 s, up to 1.5 s apart (profiles/r02g_settling_after_tuning.log): the call is
+    // over after twelve launches in a row at the chosen time (2 s), 12 s at most.
     float t = 0.f;
-    for (int k = 0, calm = 0; k < 48 && calm < 4; k++) {   // four launches in a row at the chosen time (the wipe comes in bursts), 8 s at most
+    for (int k = 0, calm = 0; k < 72 && calm < 12; k++) {
         if ((rc = launch(&t))) return rc;
-        calm = t <= best_ms * 1.01f ? calm + 1 : 0;
+        calm = t <= best_ms * 1.015f ? calm + 1 : 0;
     }
     if (final_ms) *final_ms = t;
     return BSGS_OK;
