@@ -316,7 +316,7 @@ extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz,
     if (ht_items * line_bytes + ovf_cap * 8 > fr) return fail(BSGS_ERR_NOMEM, "extended table needs %.1f GiB, %.1f GiB free", (ht_items * line_bytes + ovf_cap * 8) / 1073741824.0, fr / 1073741824.0);
     u32x4 *lines = nullptr;
     u64 *ovf = nullptr;
-    HIPCHK(bsgs_big_malloc(&lines, ht_items * line_bytes));
+    HIPCHK(bsgs_lines_malloc(d, (void **)&lines, ht_items * line_bytes));
     hipError_t e = hipMalloc(&ovf, ovf_cap * 8);
     if (e != hipSuccess) { (void)hipFree(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
     uint64_t n = 0, ob = 0;

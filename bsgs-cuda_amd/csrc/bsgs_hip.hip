@@ -29,6 +29,8 @@ extern "C" const char *bsgs_last_error(void) { return g_err.c_str(); }
 extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
 
 static void release_pending(bsgs_dev *d);
+static void free_chain_pieces(bsgs_dev *d);
+static void release_grader(bsgs_dev *d);
 
 static std::atomic<uint64_t> g_alloc_contiguous{0}, g_alloc_plain{0};
 // bytes of big buffers this process obtained as physically contiguous memory / as ordinary pages (cumulative)
@@ -101,6 +103,7 @@ static void free_g2(bsgs_dev *d)
 {
     if (d->g2) (void)hipFree(d->g2);
     if (d->chain) (void)hipFree(d->chain);
+    free_chain_pieces(d);
     if (d->schain) (void)hipFree(d->schain);
     if (d->pool) (void)hipFree(d->pool);
     d->pool = nullptr;
@@ -116,6 +119,7 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     (void)hipStreamSynchronize(d->stream);
     release_pending(d);
     free_table(d); free_g2(d);
+    release_grader(d);
     if (d->hitbuf) (void)hipFree(d->hitbuf);
     if (d->hit_host) (void)hipHostFree(d->hit_host);
     if (d->cen_dev) (void)hipFree(d->cen_dev);
@@ -221,6 +225,156 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     return BSGS_OK;
 }
 
+// ---- graded chain-scratch pieces ------------------------------------------------------------------------------------------
+// An MI355X has two classes of physical memory (64...90 GiB of the 288 GB in the smaller one; which addresses, differs per box and per
+// process): a latency-sensitive gather runs at 42-43 G rows/s in one and 38-39 G in the other, 4 GiB granules are almost always purely
+// one or the other (tools/experiments/hbm_map.hip).  The tile kernel's launch time follows them: +2...2.5 ms per 4 GiB of CHAIN SCRATCH
+// in the gather-slow class, and -2.5 ms per 4 GiB of BUCKET LINES in it (profiles/r02i_launch_time_vs_memory_class.log) -- the random
+// probes and the scratch streams want to be apart.  hipMalloc hands out whatever comes, hence the run-to-run "levels" (DESIGN.md 6).
+// So the scratch of the default kernel is allocated in pieces of about 4 GiB, every piece is graded with that gather (2 ms), pieces
+// of the gather-slow class are set aside (and freed at the end: released earlier they would be handed out again), and the kernel finds
+// tile t in piece t >> k.  BSGS_CHAIN_PIECES=0 switches back to one hipMalloc'ed buffer.
+static __global__ void grade_gather_kernel(const unsigned long long *base, const unsigned long long *idx, unsigned long long *out, unsigned long long n, unsigned long long rows)
+{
+    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base[(idx[i] % rows) * 8];
+}
+static __global__ void grade_fill_kernel(unsigned long long *idx, unsigned long long n)
+{
+    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
+    if (i < n) { unsigned long long s = (i + 1) * 0x9E3779B97F4A7C15ull; s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32; idx[i] = s >> 8; }
+}
+// The grade is RELATIVE TO THE GRADER'S OWN BUFFERS: the same piece graded 39 by one pair of index/output buffers grades 42 by another
+// pair allocated elsewhere (profiles/r02i_grade_is_relative_to_the_graders_buffers.log) -- what the gather measures is whether its random
+// reads share a memory group with its two streams.  So one pair of buffers per engine, kept for its life, grades everything: the bucket
+// lines are put where the grade is LOW (the grader's group), the chain scratch where it is HIGH (another group), and the probes and
+// the scratch streams end up apart.
+struct PieceGrader {
+    static constexpr unsigned long long N = 1ull << 24;
+    bsgs_dev *d;
+    explicit PieceGrader(bsgs_dev *dev) : d(dev) {}
+    bool init()
+    {
+        if (d->grade_idx) return true;
+        if (hipMalloc(&d->grade_idx, N * 8) != hipSuccess || hipMalloc(&d->grade_out, N * 8) != hipSuccess ||
+            hipEventCreate(&d->grade_ea) != hipSuccess || hipEventCreate(&d->grade_eb) != hipSuccess) {
+            (void)hipGetLastError();
+            release(d);
+            return false;
+        }
+        hipLaunchKernelGGL(grade_fill_kernel, dim3(N / 256), dim3(256), 0, d->stream, d->grade_idx, N);
+        return hipGetLastError() == hipSuccess;
+    }
+    static void release(bsgs_dev *d)
+    {
+        if (d->grade_idx) (void)hipFree(d->grade_idx);
+        if (d->grade_out) (void)hipFree(d->grade_out);
+        if (d->grade_ea) (void)hipEventDestroy(d->grade_ea);
+        if (d->grade_eb) (void)hipEventDestroy(d->grade_eb);
+        d->grade_idx = d->grade_out = nullptr; d->grade_ea = d->grade_eb = nullptr;
+    }
+    float grade(const void *buf, uint64_t bytes)                 // G gathers/s over the first 4 GiB (or all) of buf; 0 on error
+    {
+        const unsigned long long rows = std::min<uint64_t>(bytes, 4ull << 30) / 64;
+        float ms = 0.f;
+        hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)buf, d->grade_idx, d->grade_out, N, rows);
+        if (hipEventRecord(d->grade_ea, d->stream) != hipSuccess) return 0.f;
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)buf, d->grade_idx, d->grade_out, N, rows);
+        if (hipEventRecord(d->grade_eb, d->stream) != hipSuccess || hipEventSynchronize(d->grade_eb) != hipSuccess || hipEventElapsedTime(&ms, d->grade_ea, d->grade_eb) != hipSuccess || ms <= 0.f) return 0.f;
+        return (float)(3.0 * N / (ms * 1e6));
+    }
+};
+static void release_grader(bsgs_dev *d) { PieceGrader::release(d); }
+static void free_chain_pieces(bsgs_dev *d)
+{
+    for (u32x4 *p : d->chain_pieces) (void)hipFree(p);
+    d->chain_pieces.clear();
+    d->chain_piece_bytes = 0;
+}
+// npieces buffers of piece_bytes each, preferring the gather-fast class; false = not enough memory (nothing is left allocated)
+static bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
+{
+    struct Cand { void *p; float g; };
+    std::vector<Cand> cands;
+    PieceGrader G(d);
+    const bool can_grade = G.init();
+    const size_t extra = can_grade ? 24 : 0;                  // at most this many more than needed (the slow class holds 16...22 granules of 4 GiB)
+    float best = 0.f;
+    auto good = [&]() { size_t n = 0; for (const Cand &c : cands) n += c.g >= 0.94f * best; return n; };
+    while (cands.size() < npieces + extra) {
+        if (cands.size() >= npieces && (!can_grade || good() >= npieces)) break;
+        size_t fr = 0, tot = 0;
+        if (cands.size() >= npieces && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece_bytes + (6ull << 30))) break;   // leave room for the rest of the engine
+        void *p = nullptr;
+        if (hipMalloc(&p, piece_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        const float g = can_grade ? G.grade(p, piece_bytes) : 1.f;
+        best = std::max(best, g);
+        cands.push_back({p, g});
+    }
+    if (cands.size() < npieces) { for (const Cand &c : cands) (void)hipFree(c.p); return false; }
+    std::stable_sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.g > y.g; });
+    (void)hipStreamSynchronize(d->stream);
+    d->chain_pieces.clear();
+    for (size_t k = 0; k < npieces; k++) d->chain_pieces.push_back((u32x4 *)cands[k].p);
+    std::sort(d->chain_pieces.begin(), d->chain_pieces.end());
+    for (size_t k = npieces; k < cands.size(); k++) (void)hipFree(cands[k].p);
+    d->chain_graded = (uint32_t)cands.size(); d->chain_rejected = (uint32_t)(cands.size() - npieces);
+    d->chain_grade_best = cands[0].g; d->chain_grade_worst = cands[npieces - 1].g;
+    if (getenv("BSGS_TUNE_VERBOSE")) {
+        fprintf(stderr, "[chain pieces] %zu x %.2f GiB, graded %zu:", npieces, piece_bytes / 1073741824.0, cands.size());
+        for (size_t k = 0; k < cands.size(); k++) fprintf(stderr, "%s%.1f", k == npieces ? " | rejected " : " ", cands[k].g);
+        fprintf(stderr, "\n");
+    }
+    return true;
+}
+
+// The bucket lines want the OTHER class (the gather-slow one): with the lines there and the scratch in the gather-fast class the kernel
+// runs at 160...165 ms per 192-tile launch on every box tried; with both in the gather-fast class anywhere between 164 and 184 ms
+// (profiles/r02i_launch_time_vs_memory_class.log).  The lines are one array, so whole candidates are graded: up to ten allocations of
+// the full size are held at once, the one with the lowest mean grade over its 4 GiB slices is kept.  Tables above 40 GiB do not fit the
+// small class anyway and take what comes.  BSGS_GRADED_LINES=0: plain allocation.
+hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
+{
+    static const bool on = !(getenv("BSGS_GRADED_LINES") && atoi(getenv("BSGS_GRADED_LINES")) == 0);
+    if (!on || !d || bytes < (4ull << 30) || bytes > (40ull << 30)) return bsgs_big_malloc(out, bytes);
+    PieceGrader G(d);
+    if (!G.init()) return bsgs_big_malloc(out, bytes);
+    struct Cand { void *p; float mean, hi; };
+    std::vector<Cand> cands;
+    float top = 0.f;                                          // the highest slice grade seen: the gather-fast class
+    for (int k = 0; k < 10; k++) {
+        size_t fr = 0, tot = 0;
+        if (k && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + (48ull << 30))) break;      // keep room for the chain scratch
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        Cand c = {p, 0.f, 0.f};
+        int n = 0;
+        for (uint64_t off = 0; off + (1ull << 30) <= bytes; off += 4ull << 30, n++) {
+            const float g = G.grade((const char *)p + off, std::min<uint64_t>(bytes - off, 4ull << 30));
+            c.mean += g; c.hi = std::max(c.hi, g);
+        }
+        c.mean /= (float)std::max(n, 1);
+        top = std::max(top, c.hi);
+        cands.push_back(c);
+        bool found = false;                                   // a candidate wholly in the slow class, and the fast class has been seen
+        for (const Cand &x : cands) found |= x.hi <= 0.93f * top;       // classes seen: 38.2-39.8 | 40.5-41.4 (no good for the lines either) | 41.7-43.5
+        if (found) break;
+    }
+    if (cands.empty()) return hipErrorOutOfMemory;
+    size_t best = 0;
+    for (size_t k = 1; k < cands.size(); k++) if (cands[k].mean < cands[best].mean) best = k;
+    (void)hipStreamSynchronize(d->stream);
+    for (size_t k = 0; k < cands.size(); k++) if (k != best) (void)hipFree(cands[k].p);
+    if (getenv("BSGS_TUNE_VERBOSE")) {
+        fprintf(stderr, "[lines] %.1f GiB, %zu candidates, mean grades:", bytes / 1073741824.0, cands.size());
+        for (size_t k = 0; k < cands.size(); k++) fprintf(stderr, " %.1f%s", cands[k].mean, k == best ? "*" : "");
+        fprintf(stderr, "\n");
+    }
+    d->lines_graded = (uint32_t)cands.size(); d->lines_grade = cands[best].mean; d->lines_grade_top = top;
+    *out = cands[best].p;
+    return hipSuccess;
+}
+
 // the prefix-product scratch: 32 bytes per giant per tile in flight (16 for the pair-batched default kernel, which stores
 // one product per two giants); `full` = the caller is a generator kernel that needs the per-giant chain of one tile
 static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
@@ -232,8 +386,37 @@ static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
     d->chain_pad = halfchain ? (uint32_t)(pad_env / 16) : 0;
     // the pair-batched kernel's scratch is [tile][block][pair][2][block size]: whole blocks (the tail block is padded)
     const uint64_t threads_padded = ((uint64_t)d->Ti + d->block_size - 1) / d->block_size * d->block_size;
-    const uint64_t per_stream = ((halfchain ? threads_padded * d->pi * 16 : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16) * tiles;
+    const uint64_t per_tile = (halfchain ? threads_padded * d->pi * 16 : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16;
+    const uint64_t per_stream = per_tile * tiles;
     const uint64_t bytes = per_stream * (d->nstreams == 2 ? 2 : 1);                 // one scratch per stream
+    static const bool pieces_on = !(getenv("BSGS_CHAIN_PIECES") && atoi(getenv("BSGS_CHAIN_PIECES")) == 0);
+    if (pieces_on && halfchain && d->nstreams == 1 && bytes >= (8ull << 30) && per_tile <= (4ull << 30)) {
+        uint32_t lg = 0;
+        while ((per_tile << (lg + 1)) <= (4ull << 30)) lg++;                       // pieces of 2^lg tiles, at most 4 GiB
+        const uint64_t piece_bytes = per_tile << lg, npieces = (tiles + (1ull << lg) - 1) >> lg;
+        if (npieces <= BSGS_CHAIN_PIECES_MAX) {
+            if (!d->chain_pieces.empty() && d->chain_piece_bytes == piece_bytes && d->chain_piece_log == lg && d->chain_pieces.size() >= npieces) return BSGS_OK;
+            HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2));
+            free_chain_pieces(d);
+            if (d->chain) { (void)hipFree(d->chain); d->chain = nullptr; }
+            d->chain_bytes = 0;
+            if (!alloc_graded_pieces(d, npieces, piece_bytes)) {
+                size_t fr = 0, tot = 0;
+                (void)hipMemGetInfo(&fr, &tot);
+                return fail(BSGS_ERR_NOMEM, "chain scratch: %llu pieces of %.1f GiB for %llu tiles in flight, %.1f of %.1f GiB free", (unsigned long long)npieces,
+                            piece_bytes / 1073741824.0, (unsigned long long)tiles, fr / 1073741824.0, tot / 1073741824.0);
+            }
+            d->chain_piece_bytes = piece_bytes; d->chain_piece_log = lg;
+            d->chain_bytes = piece_bytes * npieces;
+            d->chain_stride = per_stream / 16;
+            return BSGS_OK;
+        }
+    }
+    if (!d->chain_pieces.empty()) {                                                 // back to one buffer (a generator kernel, another variant)
+        HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2));
+        free_chain_pieces(d);
+        d->chain_bytes = 0;
+    }
     if (d->chain && d->chain_bytes >= bytes) { d->chain_stride = per_stream / 16; return BSGS_OK; }
     if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
     if (bsgs_big_malloc(&d->chain, bytes) != hipSuccess) {
@@ -348,7 +531,7 @@ static int build_lines(bsgs_dev *d, uint32_t layout, bool with_list)
 {
     const int lplog = layout == BSGS_TABLE_LINES128 ? 3 : 2;
     d->lines_bytes = d->ht_items * (64ull << (lplog - 2));
-    HIPCHK(bsgs_big_malloc(&d->lines, d->lines_bytes));
+    HIPCHK(bsgs_lines_malloc(d, (void **)&d->lines, d->lines_bytes));
     unsigned long long *cnt = nullptr, h[2] = {0, 0};
     HIPCHK(hipMalloc(&cnt, 16));
     const int blocks = (int)std::min<uint64_t>((d->ht_items + 255) / 256, 1u << 20);
@@ -505,7 +688,12 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     A.debug_flags = d->debug_flags; A.pad0 = 0;
     A.centres_dev = centres_dev; A.pool = nullptr; A.pool_cap = 0; A.pool_stride = 0;
     A.digest = d->digest ? d->digest + (uint64_t)seq * d->Ti * 2 : nullptr;
-    A.chain_pad = d->chain_pad; A.pad1 = 0;
+    A.chain_pad = d->chain_pad; A.chain_mode = 0;
+    for (int k = 0; k < BSGS_CHAIN_PIECES_MAX; k++) A.chain_piece[k] = nullptr;
+    if (!d->chain_pieces.empty()) {                        // pair-batched kernel, one stream (ensure_chain)
+        A.chain = nullptr; A.chain_mode = d->chain_piece_log + 1;
+        for (size_t k = 0; k < d->chain_pieces.size(); k++) A.chain_piece[k] = d->chain_pieces[k];
+    }
     const unsigned bs = d->block_size;
     if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) {
         // the reference's own P - G arithmetic for the listed giants; bsgs_collect drops the hot loop's records for them
@@ -627,6 +815,7 @@ static int ensure_pool(bsgs_dev *d)
         HIPCHK(hipMemcpy(d->pool, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         d->pool_cap = cap; d->pool_stride = stride;
     }
+    if (!d->chain_pieces.empty()) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); free_chain_pieces(d); d->chain_bytes = 0; }
     if (d->chain && d->chain_bytes >= bytes) return BSGS_OK;
     if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
     if (bsgs_big_malloc(&d->chain, bytes) != hipSuccess) { d->chain = nullptr; return fail(BSGS_ERR_NOMEM, "pooled chain scratch: %.1f GiB", bytes / 1073741824.0); }
@@ -648,6 +837,8 @@ static int launch_pooled(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, u
     TileArgs A;
     memset(&A, 0, sizeof A);
     A.g2 = d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
+    A.chain_mode = 0;
+    for (int k = 0; k < BSGS_CHAIN_PIECES_MAX; k++) A.chain_piece[k] = nullptr;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.centres_dev = (const fe *)dc; A.pool = d->pool; A.pool_cap = d->pool_cap; A.pool_stride = d->pool_stride;
@@ -801,6 +992,19 @@ extern "C" int bsgs_run_walk(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, 
     return bsgs_collect(d, hits, max_hits, nhits, kernel_ms);
 }
 
+// how the chain scratch of the default kernel is laid out: info[0] pieces (0 = one buffer), [1] tiles per piece, [2] pieces graded by the
+// last allocation, [3] pieces handed back, [4] candidates graded for the bucket lines; grade[0], grade[1] = best / worst grade kept
+// (G gathers/s), grade[2] = mean grade of the bucket lines kept, grade[3] = the highest slice grade seen while choosing them
+extern "C" int bsgs_chain_placement(bsgs_dev *d, uint32_t info[5], float grade[4])
+{
+    if (!d || !info || !grade) return fail(BSGS_ERR_ARG, "null");
+    info[0] = (uint32_t)d->chain_pieces.size(); info[1] = d->chain_pieces.empty() ? 0 : 1u << d->chain_piece_log;
+    info[2] = d->chain_graded; info[3] = d->chain_rejected;
+    grade[0] = d->chain_grade_best; grade[1] = d->chain_grade_worst;
+    info[4] = d->lines_graded; grade[2] = d->lines_grade; grade[3] = d->lines_grade_top;
+    return BSGS_OK;
+}
+
 // Start-up tuning of WHERE the chain scratch and the bucket lines lie.  The launch time of the tile kernel depends on the physical
 // memory the driver happened to hand out for these two buffers (159 ... 186 ms for the same 192 tiles); every allocation
 // re-draws it and the level then persists for the life of the allocation (profiles/r02g_tuned_placement_persists.log).  So: time
@@ -836,6 +1040,17 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
     if (ms_out) for (uint32_t k = 0; k < 2 * candidates; k++) ms_out[k] = 0.f;
     float best_ms = 0.f;
     int rc = BSGS_OK;
+    // the allocations before this call (graded bucket lines, graded scratch pieces) handed memory back too: wait until eight launches in a
+    // row are within 1 % of the fastest seen, 8 s at most, before anything is compared
+    {
+        float lo = 1e30f, t = 0.f;
+        for (int k = 0, calm = 0; k < 48 && calm < 8; k++) {
+            if ((rc = launch(&t))) return rc;
+            if (t < lo * 0.99f) { lo = t; calm = 0; }
+            else if (t <= lo * 1.01f) { calm++; lo = std::min(lo, t); }
+            else calm = 0;
+        }
+    }
     // ---- chain scratch
     {
         std::vector<u32x4 *> held;
@@ -844,7 +1059,8 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
         if ((rc = timed(&t))) return rc;                   // allocates the scratch if this is the first launch
         held.push_back(d->chain); ms.push_back(t);
         const uint64_t bytes = d->chain_bytes;
-        while (held.size() < candidates && room_for(bytes)) {
+        // (a scratch in graded pieces is already placed by its grade: ensure_chain)
+        while (d->chain_pieces.empty() && held.size() < candidates && room_for(bytes)) {
             void *fresh = nullptr;
             if (bsgs_big_malloc(&fresh, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
             d->chain = (u32x4 *)fresh;
@@ -855,7 +1071,7 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
         size_t best = 0;
         for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;      // a new placement has to win by 0.5 %
         (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->stream2);
-        for (size_t k = 0; k < held.size(); k++) if (k != best) (void)hipFree(held[k]);
+        for (size_t k = 0; k < held.size(); k++) if (k != best && held[k]) (void)hipFree(held[k]);
         d->chain = held[best];
         if (rc) return rc;
         if (ms_out) for (size_t k = 0; k < ms.size(); k++) ms_out[k] = ms[k];
@@ -878,6 +1094,14 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
             d->lines = (u32x4 *)fresh;
             if ((rc = timed(&t))) break;
             ms.push_back(t);
+        }
+        if (getenv("BSGS_TUNE_VERBOSE")) {
+            PieceGrader G(d);
+            if (G.init()) for (size_t k = 0; k < ms.size(); k++) {
+                fprintf(stderr, "[tune] lines candidate %zu: %.2f ms per launch; grade per 4 GiB:", k, ms[k]);
+                for (uint64_t off = 0; off + (1ull << 30) <= bytes; off += 4ull << 30) fprintf(stderr, " %.1f", G.grade((const char *)held[k] + off, std::min<uint64_t>(bytes - off, 4ull << 30)));
+                fprintf(stderr, "\n");
+            }
         }
         size_t best = 0;
         for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;
@@ -1108,7 +1332,7 @@ extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
             HIPCHK(hipMemcpyPeerAsync(d->csr, d->id, s->csr, s->id, bytes, d->stream));
         }
         if (s->lines) {
-            HIPCHK(bsgs_big_malloc(&d->lines, s->lines_bytes));
+            HIPCHK(bsgs_lines_malloc(d, (void **)&d->lines, s->lines_bytes));
             d->lines_owned = true;
             HIPCHK(hipMemcpyPeerAsync(d->lines, d->id, s->lines, s->id, s->lines_bytes, d->stream));
         }
@@ -1273,7 +1497,7 @@ extern "C" int bsgs_bench_random_read(bsgs_dev *d, uint64_t footprint_bytes, uin
 extern "C" int bsgs_debug_buffers(bsgs_dev *d, uint64_t addr[5], double *lines_random_read_gbps)
 {
     if (!d || !addr) return fail(BSGS_ERR_ARG, "null");
-    addr[0] = (uint64_t)d->lines; addr[1] = (uint64_t)d->chain; addr[2] = (uint64_t)d->g2; addr[3] = (uint64_t)d->csr; addr[4] = (uint64_t)d->cen_dev;
+    addr[0] = (uint64_t)d->lines; addr[1] = (uint64_t)(d->chain_pieces.empty() ? d->chain : d->chain_pieces[0]); addr[2] = (uint64_t)d->g2; addr[3] = (uint64_t)d->csr; addr[4] = (uint64_t)d->cen_dev;
     if (lines_random_read_gbps) {
         *lines_random_read_gbps = 0;
         if (d->lines && d->layout == BSGS_TABLE_LINES64) {
@@ -1316,8 +1540,10 @@ extern "C" int bsgs_debug_realloc(bsgs_dev *d, int which, uint64_t spacer_bytes)
         e = bsgs_big_malloc(&n, d->lines_bytes);
         if (e == hipSuccess) e = hipMemcpy(n, d->lines, d->lines_bytes, hipMemcpyDeviceToDevice);
         if (e == hipSuccess) { (void)hipFree(d->lines); d->lines = (u32x4 *)n; }
-    } else if (which == 1 && d->chain) {
-        (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0;                 // scratch: the next enqueue allocates it again
+    } else if (which == 1 && (d->chain || !d->chain_pieces.empty())) {
+        if (d->chain) (void)hipFree(d->chain);
+        free_chain_pieces(d);
+        d->chain = nullptr; d->chain_bytes = 0;                                             // scratch: the next enqueue allocates it again
     } else if (which == 3) {                                     // a new HIP stream (= possibly another hardware queue)
         hipStream_t ns = nullptr;
         e = hipStreamCreateWithFlags(&ns, hipStreamNonBlocking);

@@ -28,6 +28,15 @@ struct bsgs_dev {
     uint64_t T = 0, maxnonce = 0;
     uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
     uint64_t chain_bytes = 0, chain_stride = 0;   // size of the chain scratch; u32x4 elements per stream
+    // pair-batched kernel, one stream: the scratch in separately allocated, graded pieces of 2^chain_piece_log tiles (ensure_chain)
+    std::vector<u32x4 *> chain_pieces;
+    uint32_t chain_piece_log = 0;
+    uint64_t chain_piece_bytes = 0;
+    uint32_t chain_graded = 0, chain_rejected = 0;      // pieces graded / handed back by the last graded allocation
+    unsigned long long *grade_idx = nullptr, *grade_out = nullptr;   // the grader's index / output streams (kept for the engine's life: grades are relative to them)
+    hipEvent_t grade_ea = nullptr, grade_eb = nullptr;
+    uint32_t lines_graded = 0; float lines_grade = 0.f, lines_grade_top = 0.f;   // bsgs_lines_malloc: candidates graded, mean grade kept, top grade seen
+    float chain_grade_best = 0.f, chain_grade_worst = 0.f;   // grade (G gathers/s) of the best / worst piece kept
     uint32_t chain_pad = 0;                       // extra u32x4 elements between the scratch areas of consecutive tiles
     u32 *pool = nullptr;                   // pooled launches: per-XCD rings of free chain slots
     uint32_t pool_cap = 0, pool_stride = 0, nxcc = 0;
@@ -78,6 +87,7 @@ struct bsgs_dev {
 // the big, long-lived device buffers (bucket lines, chain scratch, giants).  BSGS_CONTIGUOUS=1: ask for physically contiguous
 // memory first (hipDeviceMallocContiguous), plain hipMalloc when that is refused.
 hipError_t bsgs_big_malloc(void **p, size_t bytes);
+hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes);       // bucket lines: the candidate in the gather-slow memory class (bsgs_hip.hip)
 template <typename T> static inline hipError_t bsgs_big_malloc(T **p, size_t bytes) { return bsgs_big_malloc((void **)p, bytes); }
 
 // shared between the translation units of the library

@@ -82,7 +82,7 @@ struct Config {
     std::string dir = ".";                         // where table / output files live
     bool ref_quirks = false;                       // -refquirks: reproduce the reference kernel's NEGMODP bug bit for bit (BSGS_FLAG_REFERENCE_QUIRKS)
     bool host_centres = false;                     // -hostcentres: tile centres added on the host and uploaded (the reference's way) instead of the device walk
-    bool no_tune = false;                          // -notune: skip the start-up tuning of the buffer placement (bsgs_tune_placement)
+    bool tune = false;                             // -tune: also choose the bucket-line placement by measurement at start-up (bsgs_tune_placement)
     std::string joblog;                            // test hook: log every dispenser / checkpoint event to this file
 };
 
@@ -109,7 +109,7 @@ static void usage(const Config &c)
            "-ext     Extended baby table built in GPU memory (no HT files); automatic for -w above the reference limit, up to 2^36\n"
            "-refquirks   Reproduce the reference kernel's -Gy borrow bug bit for bit (default: correct arithmetic, finds a superset)\n"
            "-hostcentres Add the tile centres on the host and upload them (default: derived on the GPU from the tile counter)\n"
-           "-notune      Skip the start-up tuning of where the GPU buffers lie (a few seconds; worth up to 8 %% of the rate)\n",
+           "-tune        Time a few placements of the GPU buffers at start-up and keep the fastest (the engine already places them by grade)\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
 }
 
@@ -145,7 +145,7 @@ static Config parse_args(int argc, char **argv)
         else if (a == "-ext") c.ext = true;
         else if (a == "-refquirks") c.ref_quirks = true;
         else if (a == "-hostcentres") c.host_centres = true;
-        else if (a == "-notune") c.no_tune = true;
+        else if (a == "-tune") c.tune = true;
         else if (a == "-joblog") c.joblog = next();
         else die("Unknown parameter " + a);
     }
@@ -785,7 +785,7 @@ int main(int argc, char **argv)
             uint8_t p0[64], st[64];
             hs::affine_to_le(S.walk_p0, p0, p0 + 32); hs::affine_to_le(S.pubadd, st, st + 32);
             for (bsgs_dev *d : devs) CK(bsgs_set_walk(d, p0, st));      // from here on the host only advances the counter
-            if (!c.no_tune && !tuned) {
+            if (c.tune && !tuned) {
                 // once per run: the launch time depends on which physical memory the driver handed out for the chain scratch and the
                 // bucket lines; try a few placements on every GPU (in parallel) and keep the fastest
                 tuned = true;

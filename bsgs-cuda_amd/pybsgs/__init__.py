@@ -24,7 +24,7 @@ NATIVE_SYMBOLS = [
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
-    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_debug_xcd_profile",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_debug_xcd_profile",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -369,6 +369,15 @@ class Device:
         ms = C.c_float()
         _chk(self.L.bsgs_debug_xcd_profile(self.h, first, ntiles, out, C.byref(ms)))
         return [(out[2 * x] / 1e5, int(out[2 * x + 1])) for x in range(8)], ms.value
+
+    def chain_placement(self):
+        """how the chain scratch and the bucket lines were placed (bsgs_chain_placement)"""
+        info, grade = (C.c_uint32 * 5)(), (C.c_float * 4)()
+        self.L.bsgs_chain_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
+        _chk(self.L.bsgs_chain_placement(self.h, info, grade))
+        return {"pieces": int(info[0]), "tiles_per_piece": int(info[1]), "graded": int(info[2]), "handed_back": int(info[3]),
+                "best_grade_G_per_s": round(grade[0], 2), "worst_kept_grade_G_per_s": round(grade[1], 2),
+                "lines_candidates_graded": int(info[4]), "lines_mean_grade_G_per_s": round(grade[2], 2), "top_grade_seen_G_per_s": round(grade[3], 2)}
 
     def tune_placement(self, candidates=3):
         """start-up tuning of where chain scratch and bucket lines lie (bsgs_tune_placement):
