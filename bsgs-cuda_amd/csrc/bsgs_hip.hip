@@ -10,7 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -31,6 +34,7 @@ extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
 static void release_pending(bsgs_dev *d);
 static void free_chain_pieces(bsgs_dev *d);
 static void release_grader(bsgs_dev *d);
+static void free_reserve(bsgs_dev *d);
 
 static std::atomic<uint64_t> g_alloc_contiguous{0}, g_alloc_plain{0};
 // bytes of big buffers this process obtained as physically contiguous memory / as ordinary pages (cumulative)
@@ -39,6 +43,47 @@ extern "C" int bsgs_alloc_stats(uint64_t *contiguous_bytes, uint64_t *plain_byte
     if (contiguous_bytes) *contiguous_bytes = g_alloc_contiguous.load();
     if (plain_bytes) *plain_bytes = g_alloc_plain.load();
     return BSGS_OK;
+}
+// Rejected scratch pieces are not freed while memory is plentiful: freeing tens of GiB makes the driver wipe them, which slows the GPU
+// down in bursts for seconds (profiles/r02g_settling_after_tuning.log).  They wait here -- per process, any device -- until an engine is
+// closed or an allocation fails (then everything parked on that device is released and the allocation is retried).
+static std::mutex g_park_mu;
+static std::vector<std::pair<int, void *>> g_parked;           // (device, pointer)
+static void park_release(int device)
+{
+    std::vector<void *> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_park_mu);
+        for (size_t k = 0; k < g_parked.size();) {
+            if (g_parked[k].first == device) { mine.push_back(g_parked[k].second); g_parked[k] = g_parked.back(); g_parked.pop_back(); }
+            else k++;
+        }
+    }
+    for (void *p : mine) (void)hipFree(p);
+}
+static void park(int device, void *p)
+{
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    g_parked.push_back({device, p});
+}
+static hipError_t malloc_or_unpark(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return e;
+    bool any;
+    { std::lock_guard<std::mutex> lk(g_park_mu); any = false; for (auto &x : g_parked) any |= x.first == dev; }
+    if (!any) return e;
+    park_release(dev);
+    for (int k = 0; k < 24; k++) {                             // released memory is wiped before it can be allocated again
+        e = hipMalloc(p, bytes);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        std::this_thread::sleep_for(std::chrono::milliseconds(250));
+    }
+    return e;
 }
 hipError_t bsgs_big_malloc(void **p, size_t bytes)
 {
@@ -50,7 +95,7 @@ hipError_t bsgs_big_malloc(void **p, size_t bytes)
         if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) { g_alloc_contiguous += bytes; return hipSuccess; }
         (void)hipGetLastError();                                   // refused (fragmented / too large): ordinary pages
     }
-    const hipError_t e = hipMalloc(p, bytes);
+    const hipError_t e = malloc_or_unpark(p, bytes);
     if (e == hipSuccess && bytes >= (64u << 20)) g_alloc_plain += bytes;
     return e;
 }
@@ -120,6 +165,8 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     release_pending(d);
     free_table(d); free_g2(d);
     release_grader(d);
+    free_reserve(d);
+    park_release(d->id);
     if (d->hitbuf) (void)hipFree(d->hitbuf);
     if (d->hit_host) (void)hipHostFree(d->hit_host);
     if (d->cen_dev) (void)hipFree(d->cen_dev);
@@ -225,15 +272,23 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     return BSGS_OK;
 }
 
-// ---- graded chain-scratch pieces ------------------------------------------------------------------------------------------
-// An MI355X has two classes of physical memory (64...90 GiB of the 288 GB in the smaller one; which addresses, differs per box and per
-// process): a latency-sensitive gather runs at 42-43 G rows/s in one and 38-39 G in the other, 4 GiB granules are almost always purely
-// one or the other (tools/experiments/hbm_map.hip).  The tile kernel's launch time follows them: +2...2.5 ms per 4 GiB of CHAIN SCRATCH
-// in the gather-slow class, and -2.5 ms per 4 GiB of BUCKET LINES in it (profiles/r02i_launch_time_vs_memory_class.log) -- the random
-// probes and the scratch streams want to be apart.  hipMalloc hands out whatever comes, hence the run-to-run "levels" (DESIGN.md 6).
-// So the scratch of the default kernel is allocated in pieces of about 4 GiB, every piece is graded with that gather (2 ms), pieces
-// of the gather-slow class are set aside (and freed at the end: released earlier they would be handed out again), and the kernel finds
-// tile t in piece t >> k.  BSGS_CHAIN_PIECES=0 switches back to one hipMalloc'ed buffer.
+// ---- placement by grade ---------------------------------------------------------------------------------------------------
+// An MI355X's 288 GB fall into THREE memory groups of ~89 GiB (the three ranks of its 12-high HBM3E stacks, by all appearances:
+// tools/experiments/hbm_groups.hip, profiles/r02i_hbm_three_memory_groups.log): a latency-sensitive gather -- one 8-byte load per thread
+// next to a coalesced index stream and a coalesced output stream -- runs at 38-39 G rows/s when its random reads share a group with its
+// streams and at 42-43 G when they do not; 4 GiB allocations are almost always purely in one group (a few straddle: 40.5-41.4); which
+// addresses belong to which group differs per box and per process.  The tile kernel obeys the same rule: its random probes (bucket
+// lines) and its scratch streams (chain) cost +2...2.5 ms per launch for every 4 GiB they share a group with, and hipMalloc hands out
+// whatever comes -- hence the run-to-run "levels" of 159...186 ms.  So the engine grades what it allocates, with one
+// grader per engine (a grade is RELATIVE TO THE GRADER'S BUFFERS = to the group they lie in, call it group 0):
+//   * tables up to 40 GiB lie wherever hipMalloc put them (one group, sometimes two); the chain scratch -- pieces of <= 4 GiB, tile t in
+//     piece t >> k -- is graded AGAINST THEM: the gather's random reads go all over the installed bucket lines while its two streams
+//     run through the candidate piece, which is the kernel's own conflict in 2 ms; the highest-graded pieces are kept, the others
+//     handed back at the end (released earlier they would be handed out again);
+//   * larger tables (-w 34: 128 GiB) cannot avoid two groups, so before the lines are allocated one group is RESERVED piece by piece
+//     (graded relative to a pair of buffers of the engine's own: "group 0"), the lines land in the other two, and the chain scratch
+//     is then taken from the reserve.
+// BSGS_CHAIN_PIECES=0 / BSGS_GRADED_LINES=0 switch back to plain allocations.
 static __global__ void grade_gather_kernel(const unsigned long long *base, const unsigned long long *idx, unsigned long long *out, unsigned long long n, unsigned long long rows)
 {
     const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
@@ -256,22 +311,35 @@ struct PieceGrader {
     bool init()
     {
         if (d->grade_idx) return true;
-        if (hipMalloc(&d->grade_idx, N * 8) != hipSuccess || hipMalloc(&d->grade_out, N * 8) != hipSuccess ||
-            hipEventCreate(&d->grade_ea) != hipSuccess || hipEventCreate(&d->grade_eb) != hipSuccess) {
+        if (hipMalloc(&d->grade_idx, 2 * N * 8) != hipSuccess || hipEventCreate(&d->grade_ea) != hipSuccess || hipEventCreate(&d->grade_eb) != hipSuccess) {
             (void)hipGetLastError();
             release(d);
             return false;
         }
+        d->grade_out = d->grade_idx + N;                         // both streams in one allocation: one memory group
         hipLaunchKernelGGL(grade_fill_kernel, dim3(N / 256), dim3(256), 0, d->stream, d->grade_idx, N);
         return hipGetLastError() == hipSuccess;
     }
     static void release(bsgs_dev *d)
     {
         if (d->grade_idx) (void)hipFree(d->grade_idx);
-        if (d->grade_out) (void)hipFree(d->grade_out);
         if (d->grade_ea) (void)hipEventDestroy(d->grade_ea);
         if (d->grade_eb) (void)hipEventDestroy(d->grade_eb);
         d->grade_idx = d->grade_out = nullptr; d->grade_ea = d->grade_eb = nullptr;
+    }
+    // The kernel's own conflict, measured directly: random 64-byte-row reads all over `table` (the installed bucket lines) while the
+    // index and output streams run through `piece` (free scratch: its first 256 MiB are overwritten).  Needs no buffers of its own.
+    float grade_against(const void *table, uint64_t table_bytes, void *piece)
+    {
+        if (!d->grade_ea && (hipEventCreate(&d->grade_ea) != hipSuccess || hipEventCreate(&d->grade_eb) != hipSuccess)) { (void)hipGetLastError(); return 0.f; }
+        unsigned long long *idx = (unsigned long long *)piece, *out = idx + N;
+        float ms = 0.f;
+        hipLaunchKernelGGL(grade_fill_kernel, dim3(N / 256), dim3(256), 0, d->stream, idx, N);
+        hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)table, idx, out, N, table_bytes / 64);
+        if (hipEventRecord(d->grade_ea, d->stream) != hipSuccess) return 0.f;
+        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)table, idx, out, N, table_bytes / 64);
+        if (hipEventRecord(d->grade_eb, d->stream) != hipSuccess || hipEventSynchronize(d->grade_eb) != hipSuccess || hipEventElapsedTime(&ms, d->grade_ea, d->grade_eb) != hipSuccess || ms <= 0.f) return 0.f;
+        return (float)(3.0 * N / (ms * 1e6));
     }
     float grade(const void *buf, uint64_t bytes)                 // G gathers/s over the first 4 GiB (or all) of buf; 0 on error
     {
@@ -285,6 +353,11 @@ struct PieceGrader {
     }
 };
 static void release_grader(bsgs_dev *d) { PieceGrader::release(d); }
+static void free_reserve(bsgs_dev *d)
+{
+    for (void *p : d->group0_reserve) (void)hipFree(p);
+    d->group0_reserve.clear();
+}
 static void free_chain_pieces(bsgs_dev *d)
 {
     for (u32x4 *p : d->chain_pieces) (void)hipFree(p);
@@ -294,20 +367,35 @@ static void free_chain_pieces(bsgs_dev *d)
 // npieces buffers of piece_bytes each, preferring the gather-fast class; false = not enough memory (nothing is left allocated)
 static bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
 {
+    if (!d->group0_reserve.empty() && piece_bytes <= d->group0_piece_bytes && d->group0_reserve.size() >= npieces) {
+        // a big table was installed with group 0 held back for exactly this (bsgs_lines_malloc): take the scratch from the reserve
+        d->chain_pieces.clear();
+        for (size_t k = 0; k < npieces; k++) { d->chain_pieces.push_back((u32x4 *)d->group0_reserve.back()); d->group0_reserve.pop_back(); }
+        std::sort(d->chain_pieces.begin(), d->chain_pieces.end());
+        free_reserve(d);                                          // what the scratch does not need goes back to the driver
+        d->chain_graded = d->group0_graded; d->chain_rejected = d->group0_graded - (uint32_t)npieces;
+        d->chain_grade_best = d->group0_grade_lo; d->chain_grade_worst = d->group0_grade_hi;
+        d->chain_from_reserve = 1;
+        return true;
+    }
+    free_reserve(d);
+    d->chain_from_reserve = 0;
     struct Cand { void *p; float g; };
     std::vector<Cand> cands;
     PieceGrader G(d);
-    const bool can_grade = G.init();
-    const size_t extra = can_grade ? 24 : 0;                  // at most this many more than needed (the slow class holds 16...22 granules of 4 GiB)
+    const bool direct = d->lines && d->lines_bytes >= (1ull << 30) && piece_bytes >= (512ull << 20);     // grade against the installed bucket lines
+    const bool can_grade = direct || G.init();
+    const size_t extra = can_grade ? 24 + (getenv("BSGS_GRADE_MORE") ? 24 : 0) : 0;                  // at most this many more than needed (the slow class holds 16...22 granules of 4 GiB)
     float best = 0.f;
-    auto good = [&]() { size_t n = 0; for (const Cand &c : cands) n += c.g >= 0.94f * best; return n; };
+    auto good = [&]() { size_t n = 0; for (const Cand &c : cands) n += c.g >= 0.98f * best; return n; };      // pieces sharing a group with the lines grade 6-10 % lower, straddlers 2-3 %
     while (cands.size() < npieces + extra) {
-        if (cands.size() >= npieces && (!can_grade || good() >= npieces)) break;
+        static const size_t grade_more = getenv("BSGS_GRADE_MORE") ? (size_t)atoi(getenv("BSGS_GRADE_MORE")) : 0;     // diagnostics: look at this many extra pieces
+        if (cands.size() >= npieces + grade_more && (!can_grade || good() >= npieces)) break;
         size_t fr = 0, tot = 0;
         if (cands.size() >= npieces && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece_bytes + (6ull << 30))) break;   // leave room for the rest of the engine
         void *p = nullptr;
-        if (hipMalloc(&p, piece_bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        const float g = can_grade ? G.grade(p, piece_bytes) : 1.f;
+        if ((cands.size() < npieces ? malloc_or_unpark(&p, piece_bytes) : hipMalloc(&p, piece_bytes)) != hipSuccess) { (void)hipGetLastError(); break; }
+        const float g = !can_grade ? 1.f : direct ? G.grade_against(d->lines, d->lines_bytes, p) : G.grade(p, piece_bytes);
         best = std::max(best, g);
         cands.push_back({p, g});
     }
@@ -317,7 +405,11 @@ static bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_byte
     d->chain_pieces.clear();
     for (size_t k = 0; k < npieces; k++) d->chain_pieces.push_back((u32x4 *)cands[k].p);
     std::sort(d->chain_pieces.begin(), d->chain_pieces.end());
-    for (size_t k = npieces; k < cands.size(); k++) (void)hipFree(cands[k].p);
+    {
+        size_t fr = 0, tot = 0;
+        const bool plenty = hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= (96ull << 30);
+        for (size_t k = npieces; k < cands.size(); k++) { if (plenty) park(d->id, cands[k].p); else (void)hipFree(cands[k].p); }
+    }
     d->chain_graded = (uint32_t)cands.size(); d->chain_rejected = (uint32_t)(cands.size() - npieces);
     d->chain_grade_best = cands[0].g; d->chain_grade_worst = cands[npieces - 1].g;
     if (getenv("BSGS_TUNE_VERBOSE")) {
@@ -328,51 +420,52 @@ static bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_byte
     return true;
 }
 
-// The bucket lines want the OTHER class (the gather-slow one): with the lines there and the scratch in the gather-fast class the kernel
-// runs at 160...165 ms per 192-tile launch on every box tried; with both in the gather-fast class anywhere between 164 and 184 ms
-// (profiles/r02i_launch_time_vs_memory_class.log).  The lines are one array, so whole candidates are graded: up to ten allocations of
-// the full size are held at once, the one with the lowest mean grade over its 4 GiB slices is kept.  Tables above 40 GiB do not fit the
-// small class anyway and take what comes.  BSGS_GRADED_LINES=0: plain allocation.
+// The bucket lines (see "placement by grade" above): plain up to 40 GiB; larger tables get one memory group reserved for the chain scratch first.
 hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
 {
     static const bool on = !(getenv("BSGS_GRADED_LINES") && atoi(getenv("BSGS_GRADED_LINES")) == 0);
-    if (!on || !d || bytes < (4ull << 30) || bytes > (40ull << 30)) return bsgs_big_malloc(out, bytes);
+    if (!on || !d || bytes <= (40ull << 30)) return bsgs_big_malloc(out, bytes);      // anywhere: the scratch pieces are graded against these very lines
     PieceGrader G(d);
     if (!G.init()) return bsgs_big_malloc(out, bytes);
-    struct Cand { void *p; float mean, hi; };
-    std::vector<Cand> cands;
-    float top = 0.f;                                          // the highest slice grade seen: the gather-fast class
-    for (int k = 0; k < 10; k++) {
-        size_t fr = 0, tot = 0;
-        if (k && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + (48ull << 30))) break;      // keep room for the chain scratch
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        Cand c = {p, 0.f, 0.f};
-        int n = 0;
-        for (uint64_t off = 0; off + (1ull << 30) <= bytes; off += 4ull << 30, n++) {
-            const float g = G.grade((const char *)p + off, std::min<uint64_t>(bytes - off, 4ull << 30));
-            c.mean += g; c.hi = std::max(c.hi, g);
+    {
+        // Large table: walk through the free memory in 4 GiB pieces, keep every piece of group 0 (low grade) as the reserve the chain
+        // scratch will be taken from, give the others back, THEN allocate the lines: they land in the other two groups.
+        free_reserve(d);
+        const uint64_t piece = 4ull << 30;
+        struct P { void *p; float g; };
+        std::vector<P> all;
+        float top = 0.f;
+        for (;;) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece + (2ull << 30)) break;
+            void *p = nullptr;
+            if (hipMalloc(&p, piece) != hipSuccess) { (void)hipGetLastError(); break; }
+            const float g = G.grade(p, piece);
+            top = std::max(top, g);
+            all.push_back({p, g});
         }
-        c.mean /= (float)std::max(n, 1);
-        top = std::max(top, c.hi);
-        cands.push_back(c);
-        bool found = false;                                   // a candidate wholly in the slow class, and the fast class has been seen
-        for (const Cand &x : cands) found |= x.hi <= 0.93f * top;       // classes seen: 38.2-39.8 | 40.5-41.4 (no good for the lines either) | 41.7-43.5
-        if (found) break;
+        (void)hipStreamSynchronize(d->stream);
+        float lo = 1e30f, hi = 0.f;
+        for (const P &x : all) {
+            if (x.g <= 0.93f * top && d->group0_reserve.size() < 24) { d->group0_reserve.push_back(x.p); lo = std::min(lo, x.g); hi = std::max(hi, x.g); }
+            else (void)hipFree(x.p);
+        }
+        d->group0_piece_bytes = piece; d->group0_graded = (uint32_t)all.size(); d->group0_grade_lo = lo > 1e29f ? 0.f : lo; d->group0_grade_hi = hi;
+        if (getenv("BSGS_TUNE_VERBOSE")) fprintf(stderr, "[lines] %.1f GiB: %zu pieces graded (top %.1f), %zu of group 0 held back for the chain scratch (%.1f...%.1f)\n",
+                                                 bytes / 1073741824.0, all.size(), top, d->group0_reserve.size(), d->group0_grade_lo, hi);
+        // the pieces just handed back are wiped by the driver before they can be allocated again: an allocation this large may have to wait
+        auto patient = [&](int tries) {
+            hipError_t e = hipErrorOutOfMemory;
+            for (int k = 0; k < tries && e != hipSuccess; k++) {
+                e = bsgs_big_malloc(out, bytes);
+                if (e != hipSuccess) { (void)hipGetLastError(); std::this_thread::sleep_for(std::chrono::milliseconds(250)); }
+            }
+            return e;
+        };
+        hipError_t e = patient(32);
+        if (e != hipSuccess) { free_reserve(d); e = patient(32); }         // not with the reserve in the way: without it
+        return e;
     }
-    if (cands.empty()) return hipErrorOutOfMemory;
-    size_t best = 0;
-    for (size_t k = 1; k < cands.size(); k++) if (cands[k].mean < cands[best].mean) best = k;
-    (void)hipStreamSynchronize(d->stream);
-    for (size_t k = 0; k < cands.size(); k++) if (k != best) (void)hipFree(cands[k].p);
-    if (getenv("BSGS_TUNE_VERBOSE")) {
-        fprintf(stderr, "[lines] %.1f GiB, %zu candidates, mean grades:", bytes / 1073741824.0, cands.size());
-        for (size_t k = 0; k < cands.size(); k++) fprintf(stderr, " %.1f%s", cands[k].mean, k == best ? "*" : "");
-        fprintf(stderr, "\n");
-    }
-    d->lines_graded = (uint32_t)cands.size(); d->lines_grade = cands[best].mean; d->lines_grade_top = top;
-    *out = cands[best].p;
-    return hipSuccess;
 }
 
 // the prefix-product scratch: 32 bytes per giant per tile in flight (16 for the pair-batched default kernel, which stores
@@ -445,7 +538,7 @@ static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
     const bool halfchain = (d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
     const uint64_t per_giant = halfchain ? 16 : 32;             // as ensure_chain sizes the scratch
     if (d->nstreams == 1 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
-        fr += d->chain_bytes;                                   // what is already ours counts as available
+        fr += d->chain_bytes + d->group0_reserve.size() * d->group0_piece_bytes;     // what is already ours (scratch, reserve) counts as available
         for (uint64_t mult = 4; mult > 1; mult /= 2)
             if (n * mult <= BSGS_TILES_PER_LAUNCH_MAX && n * mult * d->maxnonce * per_giant <= fr / 3) { n *= mult; break; }
     }
@@ -993,15 +1086,14 @@ extern "C" int bsgs_run_walk(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, 
 }
 
 // how the chain scratch of the default kernel is laid out: info[0] pieces (0 = one buffer), [1] tiles per piece, [2] pieces graded by the
-// last allocation, [3] pieces handed back, [4] candidates graded for the bucket lines; grade[0], grade[1] = best / worst grade kept
-// (G gathers/s), grade[2] = mean grade of the bucket lines kept, grade[3] = the highest slice grade seen while choosing them
-extern "C" int bsgs_chain_placement(bsgs_dev *d, uint32_t info[5], float grade[4])
+// last allocation, [3] pieces handed back, [4] 1 = taken from the memory group reserved while a large table was installed;
+// grade[0], grade[1] = grades of the pieces kept, best and worst (G gathers/s; against the installed bucket lines: higher = further from them)
+extern "C" int bsgs_chain_placement(bsgs_dev *d, uint32_t info[5], float grade[2])
 {
     if (!d || !info || !grade) return fail(BSGS_ERR_ARG, "null");
     info[0] = (uint32_t)d->chain_pieces.size(); info[1] = d->chain_pieces.empty() ? 0 : 1u << d->chain_piece_log;
-    info[2] = d->chain_graded; info[3] = d->chain_rejected;
+    info[2] = d->chain_graded; info[3] = d->chain_rejected; info[4] = d->chain_from_reserve;
     grade[0] = d->chain_grade_best; grade[1] = d->chain_grade_worst;
-    info[4] = d->lines_graded; grade[2] = d->lines_grade; grade[3] = d->lines_grade_top;
     return BSGS_OK;
 }
 

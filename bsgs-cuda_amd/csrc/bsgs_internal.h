@@ -33,9 +33,12 @@ struct bsgs_dev {
     uint32_t chain_piece_log = 0;
     uint64_t chain_piece_bytes = 0;
     uint32_t chain_graded = 0, chain_rejected = 0;      // pieces graded / handed back by the last graded allocation
+    std::vector<void *> group0_reserve;                 // big tables: pieces of the grader's memory group held back for the chain scratch
+    uint64_t group0_piece_bytes = 0;
+    uint32_t group0_graded = 0; float group0_grade_lo = 0.f, group0_grade_hi = 0.f;
     unsigned long long *grade_idx = nullptr, *grade_out = nullptr;   // the grader's index / output streams (kept for the engine's life: grades are relative to them)
     hipEvent_t grade_ea = nullptr, grade_eb = nullptr;
-    uint32_t lines_graded = 0; float lines_grade = 0.f, lines_grade_top = 0.f;   // bsgs_lines_malloc: candidates graded, mean grade kept, top grade seen
+    uint32_t chain_from_reserve = 0;
     float chain_grade_best = 0.f, chain_grade_worst = 0.f;   // grade (G gathers/s) of the best / worst piece kept
     uint32_t chain_pad = 0;                       // extra u32x4 elements between the scratch areas of consecutive tiles
     u32 *pool = nullptr;                   // pooled launches: per-XCD rings of free chain slots

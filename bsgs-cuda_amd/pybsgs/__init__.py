@@ -371,13 +371,12 @@ class Device:
         return [(out[2 * x] / 1e5, int(out[2 * x + 1])) for x in range(8)], ms.value
 
     def chain_placement(self):
-        """how the chain scratch and the bucket lines were placed (bsgs_chain_placement)"""
-        info, grade = (C.c_uint32 * 5)(), (C.c_float * 4)()
+        """how the chain scratch was placed (bsgs_chain_placement)"""
+        info, grade = (C.c_uint32 * 5)(), (C.c_float * 2)()
         self.L.bsgs_chain_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         _chk(self.L.bsgs_chain_placement(self.h, info, grade))
         return {"pieces": int(info[0]), "tiles_per_piece": int(info[1]), "graded": int(info[2]), "handed_back": int(info[3]),
-                "best_grade_G_per_s": round(grade[0], 2), "worst_kept_grade_G_per_s": round(grade[1], 2),
-                "lines_candidates_graded": int(info[4]), "lines_mean_grade_G_per_s": round(grade[2], 2), "top_grade_seen_G_per_s": round(grade[3], 2)}
+                "from_reserved_group": bool(info[4]), "best_grade_G_per_s": round(grade[0], 2), "worst_kept_grade_G_per_s": round(grade[1], 2)}
 
     def tune_placement(self, candidates=3):
         """start-up tuning of where chain scratch and bucket lines lie (bsgs_tune_placement):

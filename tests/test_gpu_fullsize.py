@@ -236,12 +236,11 @@ def test_hit_lists_of_two_independent_kernels_agree_under_load():
         assert n == len(hits)
         res[layout] = hits
         if layout == pybsgs.TABLE_LINES64:
-            # the default kernel's scratch (sized for a full launch of 192 tiles: 48 GiB) lies in graded pieces of 16 tiles, the 16 GiB of bucket lines were
-            # chosen among graded candidates -- and the hit lists equal those of the one-buffer CSR kernel below
+            # the default kernel's scratch (sized for a full launch of 192 tiles: 48 GiB) lies in pieces of 16 tiles graded against the 16 GiB of bucket
+            # lines -- and the hit lists equal those of the one-buffer CSR kernel below
             cp = dev.chain_placement()
             assert cp["pieces"] in (9, 12) and cp["tiles_per_piece"] == 16 and cp["handed_back"] == cp["graded"] - cp["pieces"] >= 0
-            assert cp["best_grade_G_per_s"] >= cp["worst_kept_grade_G_per_s"] > 0
-            assert cp["lines_candidates_graded"] >= 1 and 0 < cp["lines_mean_grade_G_per_s"] <= cp["top_grade_seen_G_per_s"] * 1.02
+            assert cp["best_grade_G_per_s"] >= cp["worst_kept_grade_G_per_s"] > 0 and not cp["from_reserved_group"]
     assert dev.chain_placement()["pieces"] == 0                  # the per-giant kernel took one buffer
     assert res[pybsgs.TABLE_LINES64] == res[pybsgs.TABLE_CSR]
     got = res[pybsgs.TABLE_LINES64]
