@@ -32,73 +32,7 @@ extern "C" const char *bsgs_last_error(void) { return g_err.c_str(); }
 extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
 
 static void release_pending(bsgs_dev *d);
-static void free_chain_pieces(bsgs_dev *d);
-static void release_grader(bsgs_dev *d);
-static void free_reserve(bsgs_dev *d);
 
-static std::atomic<uint64_t> g_alloc_contiguous{0}, g_alloc_plain{0};
-// bytes of big buffers this process obtained as physically contiguous memory / as ordinary pages (cumulative)
-extern "C" int bsgs_alloc_stats(uint64_t *contiguous_bytes, uint64_t *plain_bytes)
-{
-    if (contiguous_bytes) *contiguous_bytes = g_alloc_contiguous.load();
-    if (plain_bytes) *plain_bytes = g_alloc_plain.load();
-    return BSGS_OK;
-}
-// Rejected scratch pieces are not freed while memory is plentiful: freeing tens of GiB makes the driver wipe them, which slows the GPU
-// down in bursts for seconds (profiles/r02g_settling_after_tuning.log).  They wait here -- per process, any device -- until an engine is
-// closed or an allocation fails (then everything parked on that device is released and the allocation is retried).
-static std::mutex g_park_mu;
-static std::vector<std::pair<int, void *>> g_parked;           // (device, pointer)
-static void park_release(int device)
-{
-    std::vector<void *> mine;
-    {
-        std::lock_guard<std::mutex> lk(g_park_mu);
-        for (size_t k = 0; k < g_parked.size();) {
-            if (g_parked[k].first == device) { mine.push_back(g_parked[k].second); g_parked[k] = g_parked.back(); g_parked.pop_back(); }
-            else k++;
-        }
-    }
-    for (void *p : mine) (void)hipFree(p);
-}
-static void park(int device, void *p)
-{
-    std::lock_guard<std::mutex> lk(g_park_mu);
-    g_parked.push_back({device, p});
-}
-static hipError_t malloc_or_unpark(void **p, size_t bytes)
-{
-    hipError_t e = hipMalloc(p, bytes);
-    if (e == hipSuccess) return e;
-    (void)hipGetLastError();
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return e;
-    bool any;
-    { std::lock_guard<std::mutex> lk(g_park_mu); any = false; for (auto &x : g_parked) any |= x.first == dev; }
-    if (!any) return e;
-    park_release(dev);
-    for (int k = 0; k < 24; k++) {                             // released memory is wiped before it can be allocated again
-        e = hipMalloc(p, bytes);
-        if (e == hipSuccess) return e;
-        (void)hipGetLastError();
-        std::this_thread::sleep_for(std::chrono::milliseconds(250));
-    }
-    return e;
-}
-hipError_t bsgs_big_malloc(void **p, size_t bytes)
-{
-    // BSGS_CONTIGUOUS=1 asks for physically contiguous VRAM first (large page-table fragments).  It was tried as an explanation
-    // of the run-to-run levels of the tile kernel (34.6 / 36.3 / 37.4 / 39.4 G on one box with one binary) and does not remove
-    // them -- 14 runs with, 14 without: the same levels, the same mean (profiles/r02e_contiguous_allocation.log) -- so it stays off.
-    static const int mode = getenv("BSGS_CONTIGUOUS") ? atoi(getenv("BSGS_CONTIGUOUS")) : 0;
-    if (mode == 1 && bytes >= (64u << 20)) {
-        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) { g_alloc_contiguous += bytes; return hipSuccess; }
-        (void)hipGetLastError();                                   // refused (fragmented / too large): ordinary pages
-    }
-    const hipError_t e = malloc_or_unpark(p, bytes);
-    if (e == hipSuccess && bytes >= (64u << 20)) g_alloc_plain += bytes;
-    return e;
-}
 static size_t hitbuf_bytes(const bsgs_dev *d) { return 64 + (size_t)d->max_hits * 16; }
 
 extern "C" int bsgs_dev_count(int *n)
@@ -270,202 +204,6 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     d->Ti = (uint32_t)(T / m); d->pi = p * m;
     HIPCHK(bsgs_big_malloc(&d->g2, maxnonce * 64));
     return BSGS_OK;
-}
-
-// ---- placement by grade ---------------------------------------------------------------------------------------------------
-// An MI355X's 288 GB fall into THREE memory groups of ~89 GiB (the three ranks of its 12-high HBM3E stacks, by all appearances:
-// tools/experiments/hbm_groups.hip, profiles/r02i_hbm_three_memory_groups.log): a latency-sensitive gather -- one 8-byte load per thread
-// next to a coalesced index stream and a coalesced output stream -- runs at 38-39 G rows/s when its random reads share a group with its
-// streams and at 42-43 G when they do not; 4 GiB allocations are almost always purely in one group (a few straddle: 40.5-41.4); which
-// addresses belong to which group differs per box and per process.  The tile kernel obeys the same rule: its random probes (bucket
-// lines) and its scratch streams (chain) cost +2...2.5 ms per launch for every 4 GiB they share a group with, and hipMalloc hands out
-// whatever comes -- hence the run-to-run "levels" of 159...186 ms.  So the engine grades what it allocates, with one
-// grader per engine (a grade is RELATIVE TO THE GRADER'S BUFFERS = to the group they lie in, call it group 0):
-//   * tables up to 40 GiB lie wherever hipMalloc put them (one group, sometimes two); the chain scratch -- pieces of <= 4 GiB, tile t in
-//     piece t >> k -- is graded AGAINST THEM: the gather's random reads go all over the installed bucket lines while its two streams
-//     run through the candidate piece, which is the kernel's own conflict in 2 ms; the highest-graded pieces are kept, the others
-//     handed back at the end (released earlier they would be handed out again);
-//   * larger tables (-w 34: 128 GiB) cannot avoid two groups, so before the lines are allocated one group is RESERVED piece by piece
-//     (graded relative to a pair of buffers of the engine's own: "group 0"), the lines land in the other two, and the chain scratch
-//     is then taken from the reserve.
-// BSGS_CHAIN_PIECES=0 / BSGS_GRADED_LINES=0 switch back to plain allocations.
-static __global__ void grade_gather_kernel(const unsigned long long *base, const unsigned long long *idx, unsigned long long *out, unsigned long long n, unsigned long long rows)
-{
-    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
-    if (i < n) out[i] = base[(idx[i] % rows) * 8];
-}
-static __global__ void grade_fill_kernel(unsigned long long *idx, unsigned long long n)
-{
-    const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
-    if (i < n) { unsigned long long s = (i + 1) * 0x9E3779B97F4A7C15ull; s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32; idx[i] = s >> 8; }
-}
-// The grade is RELATIVE TO THE GRADER'S OWN BUFFERS: the same piece graded 39 by one pair of index/output buffers grades 42 by another
-// pair allocated elsewhere (profiles/r02i_grade_is_relative_to_the_graders_buffers.log) -- what the gather measures is whether its random
-// reads share a memory group with its two streams.  So one pair of buffers per engine, kept for its life, grades everything: the bucket
-// lines are put where the grade is LOW (the grader's group), the chain scratch where it is HIGH (another group), and the probes and
-// the scratch streams end up apart.
-struct PieceGrader {
-    static constexpr unsigned long long N = 1ull << 24;
-    bsgs_dev *d;
-    explicit PieceGrader(bsgs_dev *dev) : d(dev) {}
-    bool init()
-    {
-        if (d->grade_idx) return true;
-        if (hipMalloc(&d->grade_idx, 2 * N * 8) != hipSuccess || hipEventCreate(&d->grade_ea) != hipSuccess || hipEventCreate(&d->grade_eb) != hipSuccess) {
-            (void)hipGetLastError();
-            release(d);
-            return false;
-        }
-        d->grade_out = d->grade_idx + N;                         // both streams in one allocation: one memory group
-        hipLaunchKernelGGL(grade_fill_kernel, dim3(N / 256), dim3(256), 0, d->stream, d->grade_idx, N);
-        return hipGetLastError() == hipSuccess;
-    }
-    static void release(bsgs_dev *d)
-    {
-        if (d->grade_idx) (void)hipFree(d->grade_idx);
-        if (d->grade_ea) (void)hipEventDestroy(d->grade_ea);
-        if (d->grade_eb) (void)hipEventDestroy(d->grade_eb);
-        d->grade_idx = d->grade_out = nullptr; d->grade_ea = d->grade_eb = nullptr;
-    }
-    // The kernel's own conflict, measured directly: random 64-byte-row reads all over `table` (the installed bucket lines) while the
-    // index and output streams run through `piece` (free scratch: its first 256 MiB are overwritten).  Needs no buffers of its own.
-    float grade_against(const void *table, uint64_t table_bytes, void *piece)
-    {
-        if (!d->grade_ea && (hipEventCreate(&d->grade_ea) != hipSuccess || hipEventCreate(&d->grade_eb) != hipSuccess)) { (void)hipGetLastError(); return 0.f; }
-        unsigned long long *idx = (unsigned long long *)piece, *out = idx + N;
-        float ms = 0.f;
-        hipLaunchKernelGGL(grade_fill_kernel, dim3(N / 256), dim3(256), 0, d->stream, idx, N);
-        hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)table, idx, out, N, table_bytes / 64);
-        if (hipEventRecord(d->grade_ea, d->stream) != hipSuccess) return 0.f;
-        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)table, idx, out, N, table_bytes / 64);
-        if (hipEventRecord(d->grade_eb, d->stream) != hipSuccess || hipEventSynchronize(d->grade_eb) != hipSuccess || hipEventElapsedTime(&ms, d->grade_ea, d->grade_eb) != hipSuccess || ms <= 0.f) return 0.f;
-        return (float)(3.0 * N / (ms * 1e6));
-    }
-    float grade(const void *buf, uint64_t bytes)                 // G gathers/s over the first 4 GiB (or all) of buf; 0 on error
-    {
-        const unsigned long long rows = std::min<uint64_t>(bytes, 4ull << 30) / 64;
-        float ms = 0.f;
-        hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)buf, d->grade_idx, d->grade_out, N, rows);
-        if (hipEventRecord(d->grade_ea, d->stream) != hipSuccess) return 0.f;
-        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(grade_gather_kernel, dim3(N / 256), dim3(256), 0, d->stream, (const unsigned long long *)buf, d->grade_idx, d->grade_out, N, rows);
-        if (hipEventRecord(d->grade_eb, d->stream) != hipSuccess || hipEventSynchronize(d->grade_eb) != hipSuccess || hipEventElapsedTime(&ms, d->grade_ea, d->grade_eb) != hipSuccess || ms <= 0.f) return 0.f;
-        return (float)(3.0 * N / (ms * 1e6));
-    }
-};
-static void release_grader(bsgs_dev *d) { PieceGrader::release(d); }
-static void free_reserve(bsgs_dev *d)
-{
-    for (void *p : d->group0_reserve) (void)hipFree(p);
-    d->group0_reserve.clear();
-}
-static void free_chain_pieces(bsgs_dev *d)
-{
-    for (u32x4 *p : d->chain_pieces) (void)hipFree(p);
-    d->chain_pieces.clear();
-    d->chain_piece_bytes = 0;
-}
-// npieces buffers of piece_bytes each, preferring the gather-fast class; false = not enough memory (nothing is left allocated)
-static bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
-{
-    if (!d->group0_reserve.empty() && piece_bytes <= d->group0_piece_bytes && d->group0_reserve.size() >= npieces) {
-        // a big table was installed with group 0 held back for exactly this (bsgs_lines_malloc): take the scratch from the reserve
-        d->chain_pieces.clear();
-        for (size_t k = 0; k < npieces; k++) { d->chain_pieces.push_back((u32x4 *)d->group0_reserve.back()); d->group0_reserve.pop_back(); }
-        std::sort(d->chain_pieces.begin(), d->chain_pieces.end());
-        free_reserve(d);                                          // what the scratch does not need goes back to the driver
-        d->chain_graded = d->group0_graded; d->chain_rejected = d->group0_graded - (uint32_t)npieces;
-        d->chain_grade_best = d->group0_grade_lo; d->chain_grade_worst = d->group0_grade_hi;
-        d->chain_from_reserve = 1;
-        return true;
-    }
-    free_reserve(d);
-    d->chain_from_reserve = 0;
-    struct Cand { void *p; float g; };
-    std::vector<Cand> cands;
-    PieceGrader G(d);
-    const bool direct = d->lines && d->lines_bytes >= (1ull << 30) && piece_bytes >= (512ull << 20);     // grade against the installed bucket lines
-    const bool can_grade = direct || G.init();
-    const size_t extra = can_grade ? 24 + (getenv("BSGS_GRADE_MORE") ? 24 : 0) : 0;                  // at most this many more than needed (the slow class holds 16...22 granules of 4 GiB)
-    float best = 0.f;
-    auto good = [&]() { size_t n = 0; for (const Cand &c : cands) n += c.g >= 0.98f * best; return n; };      // pieces sharing a group with the lines grade 6-10 % lower, straddlers 2-3 %
-    while (cands.size() < npieces + extra) {
-        static const size_t grade_more = getenv("BSGS_GRADE_MORE") ? (size_t)atoi(getenv("BSGS_GRADE_MORE")) : 0;     // diagnostics: look at this many extra pieces
-        if (cands.size() >= npieces + grade_more && (!can_grade || good() >= npieces)) break;
-        size_t fr = 0, tot = 0;
-        if (cands.size() >= npieces && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece_bytes + (6ull << 30))) break;   // leave room for the rest of the engine
-        void *p = nullptr;
-        if ((cands.size() < npieces ? malloc_or_unpark(&p, piece_bytes) : hipMalloc(&p, piece_bytes)) != hipSuccess) { (void)hipGetLastError(); break; }
-        const float g = !can_grade ? 1.f : direct ? G.grade_against(d->lines, d->lines_bytes, p) : G.grade(p, piece_bytes);
-        best = std::max(best, g);
-        cands.push_back({p, g});
-    }
-    if (cands.size() < npieces) { for (const Cand &c : cands) (void)hipFree(c.p); return false; }
-    std::stable_sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.g > y.g; });
-    (void)hipStreamSynchronize(d->stream);
-    d->chain_pieces.clear();
-    for (size_t k = 0; k < npieces; k++) d->chain_pieces.push_back((u32x4 *)cands[k].p);
-    std::sort(d->chain_pieces.begin(), d->chain_pieces.end());
-    {
-        size_t fr = 0, tot = 0;
-        const bool plenty = hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= (96ull << 30);
-        for (size_t k = npieces; k < cands.size(); k++) { if (plenty) park(d->id, cands[k].p); else (void)hipFree(cands[k].p); }
-    }
-    d->chain_graded = (uint32_t)cands.size(); d->chain_rejected = (uint32_t)(cands.size() - npieces);
-    d->chain_grade_best = cands[0].g; d->chain_grade_worst = cands[npieces - 1].g;
-    if (getenv("BSGS_TUNE_VERBOSE")) {
-        fprintf(stderr, "[chain pieces] %zu x %.2f GiB, graded %zu:", npieces, piece_bytes / 1073741824.0, cands.size());
-        for (size_t k = 0; k < cands.size(); k++) fprintf(stderr, "%s%.1f", k == npieces ? " | rejected " : " ", cands[k].g);
-        fprintf(stderr, "\n");
-    }
-    return true;
-}
-
-// The bucket lines (see "placement by grade" above): plain up to 40 GiB; larger tables get one memory group reserved for the chain scratch first.
-hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
-{
-    static const bool on = !(getenv("BSGS_GRADED_LINES") && atoi(getenv("BSGS_GRADED_LINES")) == 0);
-    if (!on || !d || bytes <= (40ull << 30)) return bsgs_big_malloc(out, bytes);      // anywhere: the scratch pieces are graded against these very lines
-    PieceGrader G(d);
-    if (!G.init()) return bsgs_big_malloc(out, bytes);
-    {
-        // Large table: walk through the free memory in 4 GiB pieces, keep every piece of group 0 (low grade) as the reserve the chain
-        // scratch will be taken from, give the others back, THEN allocate the lines: they land in the other two groups.
-        free_reserve(d);
-        const uint64_t piece = 4ull << 30;
-        struct P { void *p; float g; };
-        std::vector<P> all;
-        float top = 0.f;
-        for (;;) {
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece + (2ull << 30)) break;
-            void *p = nullptr;
-            if (hipMalloc(&p, piece) != hipSuccess) { (void)hipGetLastError(); break; }
-            const float g = G.grade(p, piece);
-            top = std::max(top, g);
-            all.push_back({p, g});
-        }
-        (void)hipStreamSynchronize(d->stream);
-        float lo = 1e30f, hi = 0.f;
-        for (const P &x : all) {
-            if (x.g <= 0.93f * top && d->group0_reserve.size() < 24) { d->group0_reserve.push_back(x.p); lo = std::min(lo, x.g); hi = std::max(hi, x.g); }
-            else (void)hipFree(x.p);
-        }
-        d->group0_piece_bytes = piece; d->group0_graded = (uint32_t)all.size(); d->group0_grade_lo = lo > 1e29f ? 0.f : lo; d->group0_grade_hi = hi;
-        if (getenv("BSGS_TUNE_VERBOSE")) fprintf(stderr, "[lines] %.1f GiB: %zu pieces graded (top %.1f), %zu of group 0 held back for the chain scratch (%.1f...%.1f)\n",
-                                                 bytes / 1073741824.0, all.size(), top, d->group0_reserve.size(), d->group0_grade_lo, hi);
-        // the pieces just handed back are wiped by the driver before they can be allocated again: an allocation this large may have to wait
-        auto patient = [&](int tries) {
-            hipError_t e = hipErrorOutOfMemory;
-            for (int k = 0; k < tries && e != hipSuccess; k++) {
-                e = bsgs_big_malloc(out, bytes);
-                if (e != hipSuccess) { (void)hipGetLastError(); std::this_thread::sleep_for(std::chrono::milliseconds(250)); }
-            }
-            return e;
-        };
-        hipError_t e = patient(32);
-        if (e != hipSuccess) { free_reserve(d); e = patient(32); }         // not with the reserve in the way: without it
-        return e;
-    }
 }
 
 // the prefix-product scratch: 32 bytes per giant per tile in flight (16 for the pair-batched default kernel, which stores
@@ -1186,14 +924,6 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
             d->lines = (u32x4 *)fresh;
             if ((rc = timed(&t))) break;
             ms.push_back(t);
-        }
-        if (getenv("BSGS_TUNE_VERBOSE")) {
-            PieceGrader G(d);
-            if (G.init()) for (size_t k = 0; k < ms.size(); k++) {
-                fprintf(stderr, "[tune] lines candidate %zu: %.2f ms per launch; grade per 4 GiB:", k, ms[k]);
-                for (uint64_t off = 0; off + (1ull << 30) <= bytes; off += 4ull << 30) fprintf(stderr, " %.1f", G.grade((const char *)held[k] + off, std::min<uint64_t>(bytes - off, 4ull << 30)));
-                fprintf(stderr, "\n");
-            }
         }
         size_t best = 0;
         for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;

@@ -91,6 +91,12 @@ struct bsgs_dev {
 // memory first (hipDeviceMallocContiguous), plain hipMalloc when that is refused.
 hipError_t bsgs_big_malloc(void **p, size_t bytes);
 hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes);       // bucket lines: the candidate in the gather-slow memory class (bsgs_hip.hip)
+// placement.hip
+void free_chain_pieces(bsgs_dev *d);                        // the graded pieces of the chain scratch
+void free_reserve(bsgs_dev *d);                             // the memory group held back for the scratch of a large table
+void release_grader(bsgs_dev *d);
+void park_release(int device);                              // hand every parked piece of this device back to the driver
+bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes);     // fills d->chain_pieces; false = not enough memory
 template <typename T> static inline hipError_t bsgs_big_malloc(T **p, size_t bytes) { return bsgs_big_malloc((void **)p, bytes); }
 
 // shared between the translation units of the library
