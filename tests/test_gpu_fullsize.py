@@ -229,6 +229,10 @@ def test_hit_lists_of_two_independent_kernels_agree_under_load():
         cur = ecpy.add(cur, stride_pt)
     centres[5] = ecpy.mul((777 * 2 * w + 31337) % N)            # planted: code 1 at giant 776
     centres[143] = ecpy.mul((N - (maxnonce * 2 * w) + 99) % N)  # planted: code 2 at the last giant
+    # the default kernel's scratch lies in pieces of 16 tiles: a planted hit in the first and the last tile of every piece
+    edge_tiles = [t for k in range(9) for t in (16 * k, 16 * k + 15) if t not in (5, 143)]
+    for t in edge_tiles:
+        centres[t] = ecpy.mul(((t + 100) * 2 * w + 1000 + t) % N)     # code 1 at giant t + 99
     res = {}
     for layout in (pybsgs.TABLE_LINES64, pybsgs.TABLE_CSR):
         dev.upload_htgpu_device(img.data_ptr(), 1 << htsz, w, layout)
@@ -242,8 +246,16 @@ def test_hit_lists_of_two_independent_kernels_agree_under_load():
             assert cp["pieces"] in (9, 12) and cp["tiles_per_piece"] == 16 and cp["handed_back"] == cp["graded"] - cp["pieces"] >= 0
             assert cp["best_grade_G_per_s"] >= cp["worst_kept_grade_G_per_s"] > 0 and not cp["from_reserved_group"]
     assert dev.chain_placement()["pieces"] == 0                  # the per-giant kernel took one buffer
+    # launches of 40 tiles: three pieces, the last one half used, four launches for the 144 tiles -- the same hit list
+    dev.upload_htgpu_device(img.data_ptr(), 1 << htsz, w, pybsgs.TABLE_LINES64)
+    dev.set_tiles_per_launch(40)
+    hits40, n40, _ = dev.run(centres, 65536)
+    assert dev.chain_placement()["pieces"] == 3 and hits40 == res[pybsgs.TABLE_LINES64]
+    dev.set_tiles_per_launch(0)
     assert res[pybsgs.TABLE_LINES64] == res[pybsgs.TABLE_CSR]
     got = res[pybsgs.TABLE_LINES64]
     assert (5, 1, 776) in got and (143, 2, maxnonce - 1) in got
-    assert 2 <= len(got) <= 30
+    for t in edge_tiles:
+        assert (t, 1, t + 99) in got, t
+    assert 2 + len(edge_tiles) <= len(got) <= 30 + len(edge_tiles)
     dev.close()
