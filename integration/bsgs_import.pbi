@@ -80,4 +80,7 @@ CompilerEndIf
   bsgs_build_baby_tables(dev.i, w.q, htsz.l, *htgpu_out, *htcpu_out, install_layout.l)   ; GPU table builder: the two HT file images
   bsgs_generate_g2(dev.i, *addpubg_xy, t.l, b.l, p.l)
   bsgs_download_g2(dev.i, *image_out, bytes.i)
+  bsgs_tiles_per_launch(dev.i, *n)                                   ; how many tiles one call of bsgs_run_walk should carry (the batch GetJob dispenses)
+  bsgs_chain_placement(dev.i, *info5, *grade2)                       ; diagnostics: where the engine put its scratch (nothing to do for the host)
+  bsgs_tune_placement(dev.i, candidates.l, *ms_out, *chosen2, *final_ms)   ; optional: choose the buffer placement by timed launches as well
 EndImport
