@@ -81,8 +81,7 @@ hipError_t bsgs_big_malloc(void **p, size_t bytes)
 // streams and at 42-43 G when they do not; 4 GiB allocations are almost always purely in one group (a few straddle: 40.5-41.4); which
 // addresses belong to which group differs per box and per process.  The tile kernel obeys the same rule: its random probes (bucket
 // lines) and its scratch streams (chain) cost +2...2.5 ms per launch for every 4 GiB they share a group with, and hipMalloc hands out
-// whatever comes -- hence the run-to-run "levels" of 159...186 ms.  So the engine grades what it allocates, with one
-// grader per engine (a grade is RELATIVE TO THE GRADER'S BUFFERS = to the group they lie in, call it group 0):
+// whatever comes -- hence the run-to-run "levels" of 159...186 ms.  So the engine grades what it allocates:
 //   * tables up to 40 GiB lie wherever hipMalloc put them (one group, sometimes two); the chain scratch -- pieces of <= 4 GiB, tile t in
 //     piece t >> k -- is graded AGAINST THEM: the gather's random reads go all over the installed bucket lines while its two streams
 //     run through the candidate piece, which is the kernel's own conflict in 2 ms; the highest-graded pieces are kept, the others
@@ -101,11 +100,10 @@ static __global__ void grade_fill_kernel(unsigned long long *idx, unsigned long 
     const unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x;
     if (i < n) { unsigned long long s = (i + 1) * 0x9E3779B97F4A7C15ull; s ^= s >> 29; s *= 0xBF58476D1CE4E5B9ull; s ^= s >> 32; idx[i] = s >> 8; }
 }
-// The grade is RELATIVE TO THE GRADER'S OWN BUFFERS: the same piece graded 39 by one pair of index/output buffers grades 42 by another
-// pair allocated elsewhere (profiles/r02i_grade_is_relative_to_the_graders_buffers.log) -- what the gather measures is whether its random
-// reads share a memory group with its two streams.  So one pair of buffers per engine, kept for its life, grades everything: the bucket
-// lines are put where the grade is LOW (the grader's group), the chain scratch where it is HIGH (another group), and the probes and
-// the scratch streams end up apart.
+// A grade is relative to where the gather's streams run: the same piece grades 39 with one pair of index/output buffers and 42 with another
+// pair allocated elsewhere (profiles/r02i_grade_is_relative_to_the_graders_buffers.log).  grade_against() needs no buffers (the streams
+// run through the candidate piece itself, the random reads through the installed table); grade() -- used only to reserve a group
+// before a large table exists -- runs the streams through one 256 MiB buffer of the engine's own, kept for its life ("group 0").
 struct PieceGrader {
     static constexpr unsigned long long N = 1ull << 24;
     bsgs_dev *d;
