@@ -327,3 +327,5 @@ def test_host_centres_and_reference_quirk_flags(tmp_path):
     assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD and "Checker:" in out
     out = run(geo + ["-refquirks"], tmp_path)
     assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD and "Reference-quirk mode" in out
+    out = run(geo + ["-tune"], tmp_path)                                  # start-up choice of the buffer placement by timed launches
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD and "placement tuned" in out
