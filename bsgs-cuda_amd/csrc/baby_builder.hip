@@ -101,7 +101,7 @@ namespace {
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    hipError_t alloc(size_t n) { return bsgs_big_malloc(&p, n ? n : 1); }      // parked scratch pieces are handed back on demand
     template <class T> T *as() { return (T *)p; }
 };
 }  // namespace
@@ -221,7 +221,7 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
     const uint32_t T = 1u << 16, pi = w > (1ull << 28) ? 4096 : 512;
     const uint64_t chunk = (uint64_t)T * pi;
     size_t fr = 0, tot = 0;
-    HIPCHK(hipMemGetInfo(&fr, &tot));
+    HIPCHK(bsgs_mem_available(&fr, &tot));
     const uint64_t need = std::min(chunk, w) * 8 + (uint64_t)T * pi * 32 + (64ull << 20);     // keys, chain
     if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table build needs %.1f GiB of scratch, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
     DevBuf keys, chainb, helperb, basesb, cnt;
@@ -294,9 +294,39 @@ extern "C" int bsgs_install_table_ext_device(bsgs_dev *d, const void *lines_dev,
     if (!lines_dev || !ovf_dev) return fail(BSGS_ERR_ARG, "null");
     if (ovf_n < 2 || (ovf_n & (ovf_n - 1))) return fail(BSGS_ERR_ARG, "ovf_n must be the slot count returned by the builder (a power of two)");
     HIPCHK(hipSetDevice(d->id));
+    const bool mine = d->recv_lines && lines_dev == d->recv_lines && ovf_dev == d->recv_ovf;    // bsgs_alloc_table_ext_recv's buffers
+    if (mine) { d->recv_lines = nullptr; d->recv_ovf = nullptr; }                                  // (install_lines frees the previous table, not these)
     rc = bsgs_install_lines(d, (u32x4 *)lines_dev, layout == BSGS_TABLE_LINES128_LIST ? 3 : 2, (u64 *)ovf_dev, ovf_n, 1ull << htsz, w, overflow_buckets);
     if (rc) return rc;
-    d->lines_owned = false;                                           // borrowed: the caller keeps both buffers alive
+    d->lines_owned = mine;                                            // otherwise borrowed: the caller keeps both buffers alive
+    return BSGS_OK;
+}
+
+// Receive buffers for an extended table that arrives by broadcast (config 5: rank 0 builds, RCCL broadcasts, every rank installs).  The
+// reference uploads its htGPU buffer into memory the per-GPU thread allocated itself (1_9_7File.pb:2251, 2350, 4769-4843); here the buffers
+// come from the engine's own allocator, so a table above 40 GiB gets a memory group reserved for the chain scratch exactly as
+// bsgs_build_baby_table_ext's does (bsgs_lines_malloc) -- a caller-allocated buffer cannot.  The engine owns both buffers:
+// bsgs_install_table_ext_device on these very pointers makes them its table; bsgs_dev_close frees them if they were never installed.
+extern "C" int bsgs_alloc_table_ext_recv(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout, void **lines_dev, void **ovf_dev, uint64_t *ovf_cap)
+{
+    int rc = ext_check(d, w, htsz, layout);
+    if (rc) return rc;
+    if (!lines_dev || !ovf_dev || !ovf_cap) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    bsgs_free_table(d);
+    bsgs_free_recv(d);
+    const uint64_t ht_items = 1ull << htsz, line_bytes = layout == BSGS_TABLE_LINES128_LIST ? 128 : 64;
+    uint64_t cap = 0;
+    rc = bsgs_ext_overflow_capacity(w, htsz, layout, &cap);
+    if (rc) return rc;
+    size_t fr = 0, tot = 0;
+    HIPCHK(bsgs_mem_available(&fr, &tot));
+    if (ht_items * line_bytes + cap * 8 > fr) return fail(BSGS_ERR_NOMEM, "extended table needs %.1f GiB, %.1f GiB free", (ht_items * line_bytes + cap * 8) / 1073741824.0, fr / 1073741824.0);
+    HIPCHK(bsgs_lines_malloc(d, &d->recv_lines, ht_items * line_bytes));
+    hipError_t e = bsgs_big_malloc(&d->recv_ovf, cap * 8);
+    if (e != hipSuccess) { bsgs_free_recv(d); return fail(BSGS_ERR_HIP, "hipMalloc overflow set: %s", hipGetErrorString(e)); }
+    *lines_dev = d->recv_lines; *ovf_dev = d->recv_ovf; *ovf_cap = cap;
     return BSGS_OK;
 }
 
@@ -312,12 +342,12 @@ extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz,
     rc = bsgs_ext_overflow_capacity(w, htsz, layout, &ovf_cap);
     if (rc) return rc;
     size_t fr = 0, tot = 0;
-    HIPCHK(hipMemGetInfo(&fr, &tot));
+    HIPCHK(bsgs_mem_available(&fr, &tot));
     if (ht_items * line_bytes + ovf_cap * 8 > fr) return fail(BSGS_ERR_NOMEM, "extended table needs %.1f GiB, %.1f GiB free", (ht_items * line_bytes + ovf_cap * 8) / 1073741824.0, fr / 1073741824.0);
     u32x4 *lines = nullptr;
     u64 *ovf = nullptr;
     HIPCHK(bsgs_lines_malloc(d, (void **)&lines, ht_items * line_bytes));
-    hipError_t e = hipMalloc(&ovf, ovf_cap * 8);
+    hipError_t e = bsgs_big_malloc((void **)&ovf, ovf_cap * 8);
     if (e != hipSuccess) { (void)hipFree(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
     uint64_t n = 0, ob = 0;
     rc = ext_build_into(d, w, htsz, lplog, lines, ovf, ovf_cap, &n, &ob);

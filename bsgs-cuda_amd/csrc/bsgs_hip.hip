@@ -78,6 +78,12 @@ static void free_table(bsgs_dev *d)
     d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true; d->auto_tpl = 0;
 }
 void bsgs_free_table(bsgs_dev *d) { free_table(d); }
+void bsgs_free_recv(bsgs_dev *d)
+{
+    if (d->recv_lines) (void)hipFree(d->recv_lines);
+    if (d->recv_ovf) (void)hipFree(d->recv_ovf);
+    d->recv_lines = d->recv_ovf = nullptr;
+}
 static void free_g2(bsgs_dev *d)
 {
     if (d->g2) (void)hipFree(d->g2);
@@ -97,7 +103,7 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     (void)hipSetDevice(d->id);
     (void)hipStreamSynchronize(d->stream);
     release_pending(d);
-    free_table(d); free_g2(d);
+    free_table(d); free_g2(d); bsgs_free_recv(d);
     release_grader(d);
     free_reserve(d);
     park_release(d->id);
@@ -125,7 +131,7 @@ extern "C" int bsgs_dev_meminfo(bsgs_dev *d, uint64_t *fr, uint64_t *tot)
     if (!d) return fail(BSGS_ERR_ARG, "null");
     HIPCHK(hipSetDevice(d->id));
     size_t f = 0, t = 0;
-    HIPCHK(hipMemGetInfo(&f, &t));
+    HIPCHK(bsgs_mem_available(&f, &t));       // what this process has parked on the device is handed back on demand: it counts as free
     if (fr) *fr = f;
     if (tot) *tot = t;
     return BSGS_OK;
@@ -176,6 +182,13 @@ extern "C" int bsgs_set_flags(bsgs_dev *d, uint32_t flags)
     if (!d || (flags & ~BSGS_FLAG_REFERENCE_QUIRKS)) return fail(BSGS_ERR_ARG, "unknown flag bits %#x", flags);
     if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
     d->flags = flags;
+    return BSGS_OK;
+}
+// the tile-kernel instantiation the most recent launch used, as rocprofv3 names it (the parity tests assert they ran the SHIPPED one)
+extern "C" int bsgs_debug_last_kernel(bsgs_dev *d, char *buf, int len)
+{
+    if (!d || !buf || len <= 0) return fail(BSGS_ERR_ARG, "bad args");
+    snprintf(buf, (size_t)len, "%s", d->last_kernel);
     return BSGS_OK;
 }
 extern "C" int bsgs_launch_count(bsgs_dev *d, uint64_t *launches)
@@ -233,7 +246,7 @@ static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
             d->chain_bytes = 0;
             if (!alloc_graded_pieces(d, npieces, piece_bytes)) {
                 size_t fr = 0, tot = 0;
-                (void)hipMemGetInfo(&fr, &tot);
+                (void)bsgs_mem_available(&fr, &tot);
                 return fail(BSGS_ERR_NOMEM, "chain scratch: %llu pieces of %.1f GiB for %llu tiles in flight, %.1f of %.1f GiB free", (unsigned long long)npieces,
                             piece_bytes / 1073741824.0, (unsigned long long)tiles, fr / 1073741824.0, tot / 1073741824.0);
             }
@@ -275,7 +288,7 @@ static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
     size_t fr = 0, tot = 0;
     const bool halfchain = (d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
     const uint64_t per_giant = halfchain ? 16 : 32;             // as ensure_chain sizes the scratch
-    if (d->nstreams == 1 && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+    if (d->nstreams == 1 && bsgs_mem_available(&fr, &tot) == hipSuccess) {
         fr += d->chain_bytes + d->group0_reserve.size() * d->group0_piece_bytes;     // what is already ours (scratch, reserve) counts as available
         for (uint64_t mult = 4; mult > 1; mult /= 2)
             if (n * mult <= BSGS_TILES_PER_LAUNCH_MAX && n * mult * d->maxnonce * per_giant <= fr / 3) { n *= mult; break; }
@@ -436,7 +449,7 @@ static int finish_table(bsgs_dev *d, uint64_t ht_items, uint64_t w, uint32_t lay
         const double load = (double)w / (double)ht_items;
         layout = load <= 5.0 ? BSGS_TABLE_LINES64 : load <= 9.0 ? BSGS_TABLE_LINES64_LIST : BSGS_TABLE_LINES128_LIST;
         size_t fr = 0, tot = 0;
-        HIPCHK(hipMemGetInfo(&fr, &tot));
+        HIPCHK(bsgs_mem_available(&fr, &tot));     // parked scratch pieces are ours on demand: they must not push the table into the CSR layout
         const uint64_t need = ht_items * (layout == BSGS_TABLE_LINES128_LIST ? 128ull : 64ull);
         if (load > 20.0 || need + (1ull << 30) > fr) layout = BSGS_TABLE_CSR;
     }
@@ -490,6 +503,15 @@ extern "C" int bsgs_table_info(bsgs_dev *d, uint32_t *layout, uint64_t *device_b
     return BSGS_OK;
 }
 
+// 1 = the engine owns its bucket lines / overflow set (built by it, or received into bsgs_alloc_table_ext_recv buffers); 0 = borrowed
+extern "C" int bsgs_debug_table_owner(bsgs_dev *d, int *lines_owned)
+{
+    if (!d || !lines_owned) return fail(BSGS_ERR_ARG, "null");
+    if (!d->layout) return fail(BSGS_ERR_STATE, "no table on device");
+    *lines_owned = d->lines ? (d->lines_owned ? 1 : 0) : (d->csr_owned ? 1 : 0);
+    return BSGS_OK;
+}
+
 // ---- tiles ------------------------------------------------------------------------------------------------
 static void le_to_fe(fe &f, const uint8_t *le) { memcpy(f.v, le, 32); }
 
@@ -513,6 +535,7 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
 {
     TileArgs A;
     hipStream_t st = which ? d->stream2 : d->stream;
+    d->last_kernel = "another variant (BSGS_KERNEL_VARIANT / CSR layout / odd chain length)";
     A.g2 = d->g2; A.chain = d->chain + (which ? d->chain_stride : 0); A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
@@ -547,6 +570,8 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
         if (l128) { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<3, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<3, false>), grid, block, lds, st, A); }
         else      { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<2, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<2, false>), grid, block, lds, st, A); }
         HIPCHK(hipGetLastError());
+        d->last_kernel = l128 ? (dbg ? "giant_pair2_kernel<3, true, false>" : "giant_pair2_kernel<3, false, false>")
+                              : (dbg ? "giant_pair2_kernel<2, true, false>" : "giant_pair2_kernel<2, false, false>");
         return BSGS_OK;
     }
     if ((d->variant >= 9 && d->variant <= 11) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
@@ -866,7 +891,7 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
         *ms = (t[1] + t[2]) / 2;
         return BSGS_OK;
     };
-    auto room_for = [&](uint64_t bytes) { size_t fr = 0, tot = 0; return hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= bytes + (8ull << 30); };
+    auto room_for = [&](uint64_t bytes) { size_t fr = 0, tot = 0; return bsgs_mem_available(&fr, &tot) == hipSuccess && fr >= bytes + (8ull << 30); };
     if (ms_out) for (uint32_t k = 0; k < 2 * candidates; k++) ms_out[k] = 0.f;
     float best_ms = 0.f;
     int rc = BSGS_OK;
@@ -910,7 +935,10 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
     }
     // ---- bucket lines (only the engine's own copy can move)
     if (chosen) chosen[1] = 0;
-    if (lines_layout(d) && d->lines && d->lines_owned) {
+    // Not when the scratch lies in graded pieces -- they were graded AGAINST these very lines (alloc_graded_pieces): moving the lines would
+    // make every grade stale and could undo a reserved-group placement -- and not for tables above 40 GiB (a copy per candidate, and
+    // bsgs_lines_malloc already placed them around the reserved group).
+    if (lines_layout(d) && d->lines && d->lines_owned && d->chain_pieces.empty() && d->lines_bytes <= (40ull << 30)) {
         std::vector<u32x4 *> held;
         std::vector<float> ms;
         held.push_back(d->lines); ms.push_back(best_ms);
@@ -1145,24 +1173,39 @@ extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
         if (rc) return rc;
         if (d->Ti != s->Ti || d->pi != s->pi) return fail(BSGS_ERR_STATE, "device %d chose another batching", i);
         free_table(d);
-        HIPCHK(hipMemcpyPeerAsync(d->g2, d->id, s->g2, s->id, s->maxnonce * 64, d->stream));
-        d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->layout = s->layout; d->lines_bytes = s->lines_bytes;
-        if (s->csr) {
-            const uint64_t bytes = 4 * (s->ht_items + 1) + 4 * s->w;
-            HIPCHK(bsgs_big_malloc(&d->csr, bytes));
-            d->csr_owned = true;
-            HIPCHK(hipMemcpyPeerAsync(d->csr, d->id, s->csr, s->id, bytes, d->stream));
+        // the replica's table state (layout, sizes) is set only after every allocation and copy for this device was queued: a failure
+        // half-way leaves a device WITHOUT a table (bsgs_enqueue then refuses), never one with a layout and null pointers
+        auto replicate = [&]() -> int {
+            HIPCHK(hipMemcpyPeerAsync(d->g2, d->id, s->g2, s->id, s->maxnonce * 64, d->stream));
+            if (s->csr) {
+                const uint64_t bytes = 4 * (s->ht_items + 1) + 4 * s->w;
+                HIPCHK(bsgs_big_malloc(&d->csr, bytes));
+                d->csr_owned = true;
+                HIPCHK(hipMemcpyPeerAsync(d->csr, d->id, s->csr, s->id, bytes, d->stream));
+            }
+            if (s->lines) {
+                HIPCHK(bsgs_lines_malloc(d, (void **)&d->lines, s->lines_bytes));
+                d->lines_owned = true;
+                HIPCHK(hipMemcpyPeerAsync(d->lines, d->id, s->lines, s->id, s->lines_bytes, d->stream));
+            }
+            if (s->ovf) {
+                HIPCHK(bsgs_big_malloc((void **)&d->ovf, s->ovf_n * 8));
+                d->ovf_n = s->ovf_n;
+                HIPCHK(hipMemcpyPeerAsync(d->ovf, d->id, s->ovf, s->id, s->ovf_n * 8, d->stream));
+            }
+            return BSGS_OK;
+        };
+        rc = replicate();
+        if (rc) {
+            // drain what was queued (this device and the ones before it), drop the partial replica, report the first error
+            const std::string why = bsgs_last_error();
+            for (int k = 1; k <= i; k++) if (devs[k] && devs[k] != s) { (void)hipSetDevice(devs[k]->id); (void)hipStreamSynchronize(devs[k]->stream); }
+            (void)hipSetDevice(d->id);
+            d->lines_owned = true; d->csr_owned = true;
+            free_table(d);
+            return fail(rc, "%s", why.c_str());
         }
-        if (s->lines) {
-            HIPCHK(bsgs_lines_malloc(d, (void **)&d->lines, s->lines_bytes));
-            d->lines_owned = true;
-            HIPCHK(hipMemcpyPeerAsync(d->lines, d->id, s->lines, s->id, s->lines_bytes, d->stream));
-        }
-        if (s->ovf) {
-            HIPCHK(hipMalloc(&d->ovf, s->ovf_n * 8));
-            d->ovf_n = s->ovf_n;
-            HIPCHK(hipMemcpyPeerAsync(d->ovf, d->id, s->ovf, s->id, s->ovf_n * 8, d->stream));
-        }
+        d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->lines_bytes = s->lines_bytes; d->layout = s->layout;
     }
     for (int i = 1; i < n; i++) {
         if (devs[i] == s) continue;
@@ -1284,7 +1327,7 @@ __global__ void __launch_bounds__(256) mb_gups_kernel(const u32x4 *__restrict__ 
 
 extern "C" int bsgs_bench_random_read(bsgs_dev *d, uint64_t footprint_bytes, uint32_t granule, double *gbps, double *greads)
 {
-    if (!d || (granule != 64 && granule != 128)) return fail(BSGS_ERR_ARG, "granule must be 64 or 128");
+    if (!d || (granule != 32 && granule != 64 && granule != 128)) return fail(BSGS_ERR_ARG, "granule must be 32, 64 or 128");
     HIPCHK(hipSetDevice(d->id));
     uint64_t n = 1;
     while (n * 2 * granule <= footprint_bytes) n *= 2;         // power-of-two granule count
@@ -1299,6 +1342,7 @@ extern "C" int bsgs_bench_random_read(bsgs_dev *d, uint64_t footprint_bytes, uin
     for (int rep = 0; rep < 2; rep++) {
         HIPCHK(hipEventRecord(e0, d->stream));
         if (LP == 4) hipLaunchKernelGGL(mb_gups_kernel<4>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)buf, n - 1, iters, out, 17ull + rep);
+        else if (LP == 2) hipLaunchKernelGGL(mb_gups_kernel<2>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)buf, n - 1, iters, out, 17ull + rep);
         else         hipLaunchKernelGGL(mb_gups_kernel<8>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)buf, n - 1, iters, out, 17ull + rep);
         HIPCHK(hipEventRecord(e1, d->stream));
         HIPCHK(hipStreamSynchronize(d->stream));

@@ -85,6 +85,10 @@ struct bsgs_dev {
     bool quirk_ready = false;
     u64 *digest = nullptr;                 // bsgs_run_digest: [tile][Ti][2]
     uint64_t digest_bytes = 0;
+    // receive buffers of an extended table that arrives by broadcast (bsgs_alloc_table_ext_recv): allocated like the engine's own
+    // (bsgs_lines_malloc: tables above 40 GiB get a memory group reserved for the chain scratch), owned by the engine
+    void *recv_lines = nullptr, *recv_ovf = nullptr;
+    const char *last_kernel = "";          // the tile kernel instantiation of the most recent launch (bsgs_debug_last_kernel)
 };
 
 // the big, long-lived device buffers (bucket lines, chain scratch, giants).  BSGS_CONTIGUOUS=1: ask for physically contiguous
@@ -96,11 +100,14 @@ void free_chain_pieces(bsgs_dev *d);                        // the graded pieces
 void free_reserve(bsgs_dev *d);                             // the memory group held back for the scratch of a large table
 void release_grader(bsgs_dev *d);
 void park_release(int device);                              // hand every parked piece of this device back to the driver
+uint64_t parked_bytes(int device);                          // bytes this process has parked on the device
+hipError_t bsgs_mem_available(size_t *avail, size_t *total);   // hipMemGetInfo of the current device + what is parked there (ours on demand)
 bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes);     // fills d->chain_pieces; false = not enough memory
 template <typename T> static inline hipError_t bsgs_big_malloc(T **p, size_t bytes) { return bsgs_big_malloc((void **)p, bytes); }
 
 // shared between the translation units of the library
 void bsgs_free_table(bsgs_dev *d);
+void bsgs_free_recv(bsgs_dev *d);                            // receive buffers that were never installed
 uint64_t bsgs_ovf_slots(uint64_t entries);                   // size of the overflow hash set for `entries` keys (power of two, load <= 1/2)
 int bsgs_ovf_fill(bsgs_dev *d, const u64 *list, uint64_t n, u64 *table, uint64_t slots);   // table := hash set of list[0..n)
 // hand a finished "lines + overflow list" table to the engine (it becomes the owner of both buffers)

@@ -23,23 +23,45 @@ extern "C" int bsgs_alloc_stats(uint64_t *contiguous_bytes, uint64_t *plain_byte
 // down in bursts for seconds (profiles/r02g_settling_after_tuning.log).  They wait here -- per process, any device -- until an engine is
 // closed or an allocation fails (then everything parked on that device is released and the allocation is retried).
 static std::mutex g_park_mu;
-static std::vector<std::pair<int, void *>> g_parked;           // (device, pointer)
+struct Parked { int device; void *p; uint64_t bytes; };
+static std::vector<Parked> g_parked;
 void park_release(int device)
 {
     std::vector<void *> mine;
     {
         std::lock_guard<std::mutex> lk(g_park_mu);
         for (size_t k = 0; k < g_parked.size();) {
-            if (g_parked[k].first == device) { mine.push_back(g_parked[k].second); g_parked[k] = g_parked.back(); g_parked.pop_back(); }
+            if (g_parked[k].device == device) { mine.push_back(g_parked[k].p); g_parked[k] = g_parked.back(); g_parked.pop_back(); }
             else k++;
         }
     }
     for (void *p : mine) (void)hipFree(p);
 }
-static void park(int device, void *p)
+uint64_t parked_bytes(int device)
 {
     std::lock_guard<std::mutex> lk(g_park_mu);
-    g_parked.push_back({device, p});
+    uint64_t n = 0;
+    for (const Parked &x : g_parked) if (x.device == device) n += x.bytes;
+    return n;
+}
+// What an allocation on the current device can really get: the driver's free figure plus what this process has parked there (parked pieces
+// are handed back the moment an allocation needs them: malloc_or_unpark).  Every "does it fit" decision of the engine uses this, not the raw
+// hipMemGetInfo, so that a second table upload or a second engine on the GPU is not talked into a slower layout by memory that is ours.
+hipError_t bsgs_mem_available(size_t *avail, size_t *total)
+{
+    size_t fr = 0, tot = 0;
+    const hipError_t e = hipMemGetInfo(&fr, &tot);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) fr += parked_bytes(dev);
+    if (avail) *avail = fr;
+    if (total) *total = tot;
+    return hipSuccess;
+}
+static void park(int device, void *p, uint64_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_park_mu);
+    g_parked.push_back({device, p, bytes});
 }
 static hipError_t malloc_or_unpark(void **p, size_t bytes)
 {
@@ -49,7 +71,7 @@ static hipError_t malloc_or_unpark(void **p, size_t bytes)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return e;
     bool any;
-    { std::lock_guard<std::mutex> lk(g_park_mu); any = false; for (auto &x : g_parked) any |= x.first == dev; }
+    { std::lock_guard<std::mutex> lk(g_park_mu); any = false; for (auto &x : g_parked) any |= x.device == dev; }
     if (!any) return e;
     park_release(dev);
     for (int k = 0; k < 24; k++) {                             // released memory is wiped before it can be allocated again
@@ -208,7 +230,7 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
     {
         size_t fr = 0, tot = 0;
         const bool plenty = hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= (96ull << 30);
-        for (size_t k = npieces; k < cands.size(); k++) { if (plenty) park(d->id, cands[k].p); else (void)hipFree(cands[k].p); }
+        for (size_t k = npieces; k < cands.size(); k++) { if (plenty) park(d->id, cands[k].p, piece_bytes); else (void)hipFree(cands[k].p); }
     }
     d->chain_graded = (uint32_t)cands.size(); d->chain_rejected = (uint32_t)(cands.size() - npieces);
     d->chain_grade_best = cands[0].g; d->chain_grade_worst = cands[npieces - 1].g;
@@ -231,6 +253,7 @@ hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
         // Large table: walk through the free memory in 4 GiB pieces, keep every piece of group 0 (low grade) as the reserve the chain
         // scratch will be taken from, give the others back, THEN allocate the lines: they land in the other two groups.
         free_reserve(d);
+        park_release(d->id);                                      // everything free is about to be graded: parked pieces belong to that walk
         const uint64_t piece = 4ull << 30;
         struct P { void *p; float g; };
         std::vector<P> all;

@@ -25,6 +25,7 @@ NATIVE_SYMBOLS = [
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
     "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_debug_xcd_profile",
+    "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -96,6 +97,9 @@ def lib():
             "bsgs_ext_overflow_capacity": [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)],
             "bsgs_build_baby_table_ext_device": [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
             "bsgs_install_table_ext_device": [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32],
+            "bsgs_alloc_table_ext_recv": [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)],
+            "bsgs_debug_last_kernel": [vp, C.c_char_p, C.c_int],
+            "bsgs_debug_table_owner": [vp, C.POINTER(C.c_int)],
             "bsgs_profile_phases": [vp, u8p, C.c_uint32, C.POINTER(C.c_float)],
             "bsgs_set_walk": [vp, u8p, u8p],
             "bsgs_enqueue_walk": [vp, C.c_uint64, C.c_uint32],
@@ -229,6 +233,22 @@ class Device:
 
     def install_table_ext_device(self, lines_dptr, ovf_dptr, ovf_n, overflow_buckets, w, htsz, layout):
         _chk(self.L.bsgs_install_table_ext_device(self.h, C.c_void_p(lines_dptr), C.c_void_p(ovf_dptr), ovf_n, overflow_buckets, w, htsz, layout))
+
+    def alloc_table_ext_recv(self, w, htsz, layout):
+        """engine-owned receive buffers for a broadcast extended table: (lines_dptr, ovf_dptr, ovf_cap slots)"""
+        lines, ovf, cap = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _chk(self.L.bsgs_alloc_table_ext_recv(self.h, w, htsz, layout, C.byref(lines), C.byref(ovf), C.byref(cap)))
+        return lines.value, ovf.value, cap.value
+
+    def table_owned(self):
+        v = C.c_int()
+        _chk(self.L.bsgs_debug_table_owner(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def last_kernel(self):
+        buf = C.create_string_buffer(128)
+        _chk(self.L.bsgs_debug_last_kernel(self.h, buf, 128))
+        return buf.value.decode()
 
     def table_info(self):
         lay, nb, ov = C.c_uint32(), C.c_uint64(), C.c_uint64()

@@ -27,7 +27,8 @@ def deal_tiles(items, rank, world):
 
 
 def broadcast_table(img, src=0):
-    """start-up broadcast of the htGPU image (a torch tensor on the rank's device); returns seconds spent"""
+    """start-up broadcast of the htGPU image (a torch tensor on the rank's device); returns seconds spent.  RCCL moves device memory
+    directly; on gloo (CPU tests; bench.py --same-device: N ranks on ONE GPU) device tensors are staged through host memory in pieces."""
     import time
     if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
         return 0.0
@@ -35,12 +36,41 @@ def broadcast_table(img, src=0):
         torch.cuda.synchronize()
     t0 = time.time()
     flat = img.view(-1)
-    step = 1 << 30                                   # elements per collective: keeps every call's count far below 2^31
+    staged = img.is_cuda and td.get_backend() == "gloo"
+    step = (1 << 26) if staged else (1 << 30)        # elements per collective: keeps every call's count far below 2^31
     for s in range(0, flat.numel(), step):
-        td.broadcast(flat[s:s + step], src=src)
+        piece = flat[s:s + step]
+        if staged:
+            host = piece.cpu() if td.get_rank() == src else torch.empty(piece.shape, dtype=piece.dtype)
+            td.broadcast(host, src=src)
+            if td.get_rank() != src:
+                piece.copy_(host)
+        else:
+            td.broadcast(piece, src=src)
     if img.is_cuda:
         torch.cuda.synchronize()
     return time.time() - t0
+
+
+class DeviceMemory:
+    """a raw device allocation of the engine (pointer, bytes) as something torch can wrap without copying
+    (torch.as_tensor(DeviceMemory(...), device=...) -> uint8 tensor over the same memory): the receive buffers of a broadcast table"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def wrap_device_memory(ptr, nbytes, device):
+    return torch.as_tensor(DeviceMemory(ptr, nbytes), device=device)
+
+
+def gather_objects(obj):
+    """every rank's picklable object, in rank order, on every rank"""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [obj]
+    out = [None] * td.get_world_size()
+    td.all_gather_object(out, obj)
+    return out
 
 
 def barrier(cuda=True):

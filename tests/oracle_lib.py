@@ -98,6 +98,7 @@ def lib():
                                               C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Hit), C.c_uint64]),
             "o_tile_ref_slice_digest": (C.c_uint64, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint64,
                                                      C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(Hit), C.c_uint64, u8p]),
+            "o_tile_ref_slice_keys": (None, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, u8p]),
             "o_fast_unpack_g2": (None, [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, u8p]),
             "o_fast_tile_slice_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p, C.c_uint64, C.c_int,
                                                C.POINTER(C.c_uint64)]),
@@ -213,6 +214,15 @@ def tile_slice_digest(P, g2buf, t, b, p, htbuf, htsz, tid0, tid1, flags=0, max_h
     n = lib().o_tile_ref_slice_digest(C.byref(Pt.from_ints(*P)), ptr(g2buf), t, b, p, ptr(htbuf), 1 << htsz, flags,
                                       tid0, tid1, hits, max_hits, dg.ctypes.data_as(C.c_void_p))
     return [(hits[i].code, hits[i].idx) for i in range(min(n, max_hits))], n, dg
+
+
+def tile_slice_keys(P, g2buf, t, b, p, tid0, tid1, flags=0):
+    """every 64-bit key the reference threads [tid0, tid1) of a tile probe: uint64[(tid1-tid0), p, 2] = (x(P-G), x(P+G) | x(2P)) per giant"""
+    import numpy as np
+    keys = np.zeros((tid1 - tid0, p, 2), dtype=np.uint64)
+    ptr = g2buf.ctypes.data_as(C.c_void_p) if hasattr(g2buf, "ctypes") else C.cast(g2buf, C.c_void_p)
+    lib().o_tile_ref_slice_keys(C.byref(Pt.from_ints(*P)), ptr, t, b, p, flags, tid0, tid1, keys.ctypes.data_as(C.c_void_p))
+    return keys
 
 
 def fast_tile_slice(P, g2buf, t, b, p, htbuf, htsz, tid0, tid1, nthreads=1):

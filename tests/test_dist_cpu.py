@@ -32,9 +32,12 @@ for k, tl in mine:
     assert [list(x) for x in h] == tl["hits"]
     hits += [(k, c, i) for c, i in h]
 D.barrier(cuda=False)
+# what bench.py --dump-hits gathers: every rank's record, in rank order, on every rank
+recs = D.gather_objects({"rank": rank, "tiles": [k for k, _ in mine], "nhits": len(hits)})
+assert [r["rank"] for r in recs] == list(range(world)) and recs[rank]["nhits"] == len(hits)
 steps = D.reduce_sum_int(len(mine) * 2 * fx["t"] * fx["b"] * fx["p"])
 tmax = D.reduce_max([0.5 + rank])[0]
-json.dump({"rank": rank, "world": world, "hits": hits, "tiles": [k for k, _ in mine], "steps": steps, "tmax": tmax},
+json.dump({"rank": rank, "world": world, "gathered": recs, "hits": hits, "tiles": [k for k, _ in mine], "steps": steps, "tmax": tmax},
           open(os.path.join(OUT, "r%d.json" % rank), "w"))
 import torch.distributed as td
 td.destroy_process_group()
@@ -63,6 +66,7 @@ def test_two_ranks_gloo(tmp_path):
     assert union == expect
     assert r[0]["steps"] == r[1]["steps"] == len(tiles) * 2 * fx["t"] * fx["b"] * fx["p"]
     assert r[0]["tmax"] == r[1]["tmax"] == 1.5                                          # max over ranks
+    assert r[0]["gathered"] == r[1]["gathered"] and [g["tiles"] for g in r[0]["gathered"]] == [r[0]["tiles"], r[1]["tiles"]]
 
 
 def test_bench_gpus_flag_spawns_one_rank_per_gpu():
