@@ -14,8 +14,7 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
-typedef uint32_t u32; typedef uint64_t u64;
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#include "fp256.hip.h"       // the engine's own field arithmetic: fe_mul (Comba columns on v_mad_u64_u32 + fast fold), fe_mul512
 
 // ---------------------------------------------------------------- instruction rates
 template <int OP>
@@ -284,12 +283,159 @@ static void sustain_stream(double secs, size_t mib, u32 *dout)
     printf("{\"bench\":\"sustain\",\"op\":\"coalesced reads over %zu MiB\",\"seconds\":%.2f,\"GB_per_s\":%.1f}\n", mib, total_ms / 1e3, rd / (total_ms * 1e-3) / 1e9);
 }
 
+// ---------------------------------------------------------------- a different multiplier: FP64 fused multiply-adds
+// 256-bit operands as six 48-bit limbs held as doubles; every limb product a_i*b_j (96 bits) is split EXACTLY into its part above 2^48
+// and its part below by two fused multiply-adds, with the whole kernel in round-toward-zero:
+//     hi chain : H <- fma(a_i, b_j, H), H starting at 2^100 (ulp 2^48): H - 2^100 = 2^48 * sum floor(a_i b_j / 2^48), exactly -- free accumulation
+//     each hi  : nhi = H_before - H_after (exact) ; lo = fma(a_i, b_j, nhi) (exact, < 2^48) ; L += lo (exact, < 6 * 2^48)
+// 4 FP64 operations per limb product, 36 products, 3 per column to hand the hi sum to the next column: 177 FP64 instructions for the
+// 512-bit product in redundant form (12 column values < 2^52) -- BEFORE any reduction mod p, carry normalisation or conversion from / to the
+// 32-bit words the giants are stored in.  (5 x 52-bit limbs, the Emmart-Weems form, needs integer 64-bit adds of the bit patterns -- two
+// carry steps each on this ISA -- because five 52-bit halves do not sum exactly in a double: 7 instructions per product x 25 = 175, the same.)
+// The integer product it competes with (fe_mul512) is 64 multiply-adds + 56 carry counts + 15 moves = 135 instructions, and v_fma_f64 issues
+// at the rate of v_mad_u64_u32 (4 cycles per wave) at 29 pJ against 25 (profiles/r01h_power_ops.jsonl).
+struct fd6 { double l[6]; };
+__device__ __forceinline__ void dpf_mul512(double (&V)[12], const fd6 &a, const fd6 &b)
+{
+    const double C = 0x1p100;
+    double carry = 0.0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        double H = C, L = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 5) continue;
+            const double before = H;
+            H = __builtin_fma(a.l[i], b.l[j], H);               // round toward zero (MODE register, set by the kernel): + floor(ab / 2^48) * 2^48
+            const double nhi = before - H;
+            L += __builtin_fma(a.l[i], b.l[j], nhi);            // the low 48 bits of the product, exactly
+        }
+        V[k] = L + carry;
+        carry = (H - C) * 0x1p-48;
+    }
+    V[11] = carry;
+}
+__device__ __forceinline__ void fp64_round_toward_zero() { __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 3); }   // MODE[3:2]: f64 rounding
+__device__ __forceinline__ void fp64_round_nearest() { __builtin_amdgcn_s_setreg((1 << 11) | (2 << 6) | 1, 0); }
+
+// OP 200: fe_mul (integer, with the fold) ; 201: fe_mul512 only (integer product, no fold) ; 202: dpf_mul512 (FP64 product, no fold)
+template <int OP>
+__global__ void __launch_bounds__(256) mulrate_kernel(u32 *out, int iters, u32 seed)
+{
+    const u32 t = threadIdx.x + blockIdx.x * blockDim.x;
+    u32 r = 0;
+    if (OP == 202) {
+        fp64_round_toward_zero();
+        fd6 a, b;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { a.l[i] = (double)(((u64)(seed * 2654435761u + t * 40503u + i) << 16) | 0x1234u); b.l[i] = a.l[i] + 97.0; }
+        for (int it = 0; it < iters; it++) {
+            double V[12];
+            dpf_mul512(V, a, b);
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.l[i] = V[i] + V[i + 6];        // (6 extra additions per product: a dependency, not a reduction)
+            dpf_mul512(V, b, a);
+#pragma unroll
+            for (int i = 0; i < 6; i++) b.l[i] = V[i] + V[i + 6];
+        }
+        r = (u32)a.l[0] ^ (u32)b.l[3];
+        fp64_round_nearest();
+    } else {
+        fe a, b;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a.v[i] = seed * 2654435761u + t * 40503u + i; b.v[i] = a.v[i] ^ 0x9E3779B9u; }
+        for (int it = 0; it < iters; it++) {
+            if (OP == 200) { fe_mul(a, a, b); fe_mul(b, b, a); }
+            else {
+                u32 w[16];
+                fe_mul512(w, a.v, b.v);
+#pragma unroll
+                for (int i = 0; i < 8; i++) a.v[i] = w[i] ^ w[i + 8];     // (8 extra xors per product)
+                fe_mul512(w, b.v, a.v);
+#pragma unroll
+                for (int i = 0; i < 8; i++) b.v[i] = w[i] ^ w[i + 8];
+            }
+        }
+        r = a.v[0] ^ b.v[3];
+    }
+    if (r == 0x12345678u) out[t] = r;
+}
+template <int OP>
+static void sustain_mul(const char *name, double secs, u32 *dout)
+{
+    const int blocks = 256 * 8, threads = 256, iters = 4000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double total_ms = 0, n = 0;
+    hipLaunchKernelGGL(mulrate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, dout, 10, 1u);
+    CK(hipDeviceSynchronize());
+    while (total_ms < secs * 1e3) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(mulrate_kernel<OP>, dim3(blocks), dim3(threads), 0, 0, dout, iters, 2u);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms; n += (double)blocks * threads * iters * 2.0;
+    }
+    printf("{\"bench\":\"sustain\",\"op\":\"%s\",\"seconds\":%.2f,\"Gmul_per_s\":%.1f}\n", name, total_ms / 1e3, n / (total_ms * 1e-3) / 1e9);
+}
+
+// correctness of dpf_mul512 against exact integer arithmetic on the host: 2^16 random operand pairs
+__global__ void dpf_check_kernel(const double *a_in, const double *b_in, double *v_out, int n)
+{
+    const int t = threadIdx.x + blockIdx.x * blockDim.x;
+    if (t >= n) return;
+    fp64_round_toward_zero();
+    fd6 a, b;
+    for (int i = 0; i < 6; i++) { a.l[i] = a_in[t * 6 + i]; b.l[i] = b_in[t * 6 + i]; }
+    double V[12];
+    dpf_mul512(V, a, b);
+    for (int k = 0; k < 12; k++) v_out[t * 12 + k] = V[k];
+    fp64_round_nearest();
+}
+static int dpf_check()
+{
+    const int n = 1 << 16;
+    std::vector<double> a(n * 6), b(n * 6), v(n * 12);
+    u64 s = 0x1234567;
+    auto rnd48 = [&]() { s += 0x9E3779B97F4A7C15ULL; u64 z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return (z ^ (z >> 31)) & 0xFFFFFFFFFFFFULL; };
+    for (int t = 0; t < n; t++)
+        for (int i = 0; i < 6; i++) {
+            u64 x = rnd48(), y = rnd48();
+            if (t < 64) { x = (t & 1) ? 0xFFFFFFFFFFFFULL : (t & 2 ? 0 : x); y = (t & 4) ? 0xFFFFFFFFFFFFULL : (t & 8 ? 1 : y); }   // extremes first
+            a[t * 6 + i] = (double)x; b[t * 6 + i] = (double)y;
+        }
+    double *da, *db, *dv;
+    CK(hipMalloc(&da, a.size() * 8)); CK(hipMalloc(&db, b.size() * 8)); CK(hipMalloc(&dv, v.size() * 8));
+    CK(hipMemcpy(da, a.data(), a.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dpf_check_kernel, dim3(n / 256), dim3(256), 0, 0, da, db, dv, n);
+    CK(hipMemcpy(v.data(), dv, v.size() * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int t = 0; t < n; t++) {
+        unsigned __int128 col[12] = {0}, got[12] = {0};
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) col[i + j] += (unsigned __int128)(u64)a[t * 6 + i] * (u64)b[t * 6 + j];
+        for (int k = 0; k < 12; k++) got[k] = (unsigned __int128)(u64)v[t * 12 + k];
+        unsigned __int128 c1 = 0, c2 = 0;          // normalise both to 48-bit limbs and compare
+        for (int k = 0; k < 12; k++) {
+            c1 += col[k]; c2 += got[k];
+            if ((u64)(c1 & 0xFFFFFFFFFFFFULL) != (u64)(c2 & 0xFFFFFFFFFFFFULL)) { bad++; break; }
+            c1 >>= 48; c2 >>= 48;
+        }
+    }
+    printf("{\"bench\":\"dpf_check\",\"cases\":%d,\"mismatches\":%d}\n", n, bad);
+    return bad;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && !strcmp(argv[1], "dpfcheck")) return dpf_check() ? 1 : 0;
     if (argc >= 4 && !strcmp(argv[1], "power")) {
         u32 *dout; CK(hipMalloc(&dout, 256 * 8 * 256 * 4));
         const int op = atoi(argv[2]); const double secs = atof(argv[3]);
         switch (op) {
+        case 200: sustain_mul<200>("fe_mul: integer 256x256 product + fold mod p (the engine's multiplier)", secs, dout); break;
+        case 201: sustain_mul<201>("fe_mul512: integer 256x256->512 product only", secs, dout); break;
+        case 202: sustain_mul<202>("dpf_mul512: FP64 6x48-bit-limb 288x288->576 product only (no fold, no normalisation, no conversion)", secs, dout); break;
+        case 105: sustain_gups<2>(secs, 16384, dout); break;       // 32-byte half lines: 2 lanes x 16 B
         case 100: sustain_gups<4>(secs, 16384, dout); break;
         case 101: sustain_gups<8>(secs, 16384, dout); break;
         case 102: sustain_gups<4>(secs, 16, dout); break;          // L2-resident footprint
@@ -333,6 +479,7 @@ int main(int argc, char **argv)
             run_gups<4, 4>((const u32x4*)buf, bytes, dout, wps);    // 64 B
             run_gups<4, 8>((const u32x4*)buf, bytes, dout, wps);    // 64 B, deeper
             run_gups<8, 4>((const u32x4*)buf, bytes, dout, wps);    // 128 B
+            run_gups_coop<2, 8>((const u32x4*)buf, bytes, dout, wps);   // 32 B by 2 lanes
             run_gups_coop<4, 8>((const u32x4*)buf, bytes, dout, wps);   // 64 B by 4 lanes
             run_gups_coop<8, 8>((const u32x4*)buf, bytes, dout, wps);   // 128 B by 8 lanes
         }
