@@ -754,10 +754,24 @@ int main(int argc, char **argv)
         const auto t0 = std::chrono::steady_clock::now();
         for (size_t gi = 0; gi < gpus.size(); gi++) devs[gi] = open_dev(gpus[gi]);
         load_first(S, gpus[0], devs[0], htgpu, g2);
+        // the chain scratch, placed by grade, is part of the start-up (the reference's cuMemAlloc_v2 before its loop, 1_9_7File.pb:2251), and
+        // it is allocated BEFORE the replicas: an engine that reserved a memory group for it (tables above 40 GiB) hands the unused part of
+        // the reserve back here, which matters when a second engine shares the GPU (-d 0,0)
+        auto prepare = [&](size_t gi) {
+            CK(bsgs_prepare(devs[gi]));
+            uint32_t info[5] = {0, 0, 0, 0, 0}; float grade[2] = {0.f, 0.f};
+            CK(bsgs_chain_placement(devs[gi], info, grade));
+            printf("GPU #%d engine %zu: chain scratch in %u piece(s) of %u tiles, %u graded, reserved memory group: %s\n", gpus[gi], gi, info[0], info[1], info[2],
+                   info[4] ? "yes" : "no");
+        };
+        prepare(0);
         if (devs.size() > 1) {
+            const auto t1 = std::chrono::steady_clock::now();
             CK(bsgs_broadcast_tables(devs.data(), (int)devs.size()));
-            printf("Tables replicated to %zu more GPU engine(s) device-to-device in %.2fs\n", devs.size() - 1, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            printf("Tables replicated to %zu more GPU engine(s) device-to-device in %.2fs\n", devs.size() - 1, std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+            for (size_t gi = 1; gi < devs.size(); gi++) prepare(gi);
         }
+        (void)t0;
         if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }
     }
     if (!c.joblog.empty()) { S.joblog = fopen(c.joblog.c_str(), "w"); if (!S.joblog) die("Can`t create " + c.joblog); }
@@ -765,7 +779,7 @@ int main(int argc, char **argv)
     std::vector<uint8_t>().swap(g2);
 
     int finditems = 0;
-    bool tuned = false, prepared = false;
+    bool tuned = false;
     for (size_t li = 0; li < pubs.size(); li++) {
         S.listpos = (int)li + 1;
         if (recovery && S.listpos != rec_pos) continue;
@@ -804,15 +818,6 @@ int main(int argc, char **argv)
                     printf("GPU #%d: placement tuned, %.1f -> %.1f ms per launch\n", gpus[gi], res[gi][0], res[gi][6]);
                 }
             }
-        }
-        if (!prepared) {                                                // the chain scratch (placed by grade) belongs to the start-up, like the
-            prepared = true;                                            // reference's cuMemAlloc_v2 before its loop (1_9_7File.pb:2251): not on the job's clock
-            std::vector<std::thread> tp;
-            std::vector<int> rcs(devs.size(), 0);
-            std::vector<std::string> why(devs.size());
-            for (size_t gi = 0; gi < devs.size(); gi++) tp.emplace_back([&, gi]() { rcs[gi] = bsgs_prepare(devs[gi]); if (rcs[gi]) why[gi] = bsgs_last_error(); });
-            for (auto &t : tp) t.join();
-            for (size_t gi = 0; gi < devs.size(); gi++) if (rcs[gi]) die("error bsgs_prepare-" + std::to_string(rcs[gi]) + ": " + why[gi]);
         }
         S.past_end = false;
         S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0; S.hits_checked = 0; S.checker_ns = 0;
