@@ -24,7 +24,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = os.environ.get("ISA_KERNEL", "_Z18giant_pair2_kernelILi2ELb0ELb0ELb0EEv8TileArgs")
+KERNEL = os.environ.get("ISA_KERNEL", "_Z18giant_pair2_kernelILi2ELb0ELb0EEv8TileArgs")
 COST = {"mad64": 4.2, "carry": 4.1, "plain": 2.3}
 
 

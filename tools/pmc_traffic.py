@@ -78,6 +78,17 @@ def main():
             res["valu_int64_instructions_per_step"] = i64 * 64 / steps
     except Exception as e:
         res["config_error"] = repr(e)
+    # launch times: of the plain process, of the process under the kernel trace, and of every PMC pass (a counter pass runs 3-5 % slower)
+    def launch_ms(name):
+        try:
+            line = [x for x in open(os.path.join(d, name)).read().splitlines() if x.startswith("{")][-1]
+            return json.loads(line)["roofline"]["avg_launch_ms"]
+        except Exception:
+            return None
+    res["avg_launch_ms_plain_process"] = launch_ms("bench_plain.json")
+    res["avg_launch_ms_under_kernel_trace"] = launch_ms("bench_under_rocprofv3_stats.json")
+    res["avg_launch_ms_under_pmc"] = {n[len("bench_under_pmc_"):-5]: launch_ms(n) for n in sorted(os.listdir(d)) if n.startswith("bench_under_pmc_")}
+    res["avg_launch_ms"] = res["avg_launch_ms_under_pmc"].get("VALUBusy") or res["avg_launch_ms_under_pmc"].get("FETCH_SIZE")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res)[:600])
 
