@@ -761,7 +761,7 @@ int main(int argc, char **argv)
             CK(bsgs_prepare(devs[gi]));
             uint32_t info[5] = {0, 0, 0, 0, 0}; float grade[2] = {0.f, 0.f};
             CK(bsgs_chain_placement(devs[gi], info, grade));
-            printf("GPU #%d engine %zu: chain scratch in %u piece(s) of %u tiles, %u graded, reserved memory group: %s\n", gpus[gi], gi, info[0], info[1], info[2],
+            printf("GPU #%d engine %zu: chain scratch in %u piece(s) of %u tiles, %u graded, reserved group: %s\n", gpus[gi], gi, info[0], info[1], info[2],
                    info[4] ? "yes" : "no");
         };
         prepare(0);
