@@ -85,3 +85,30 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="8", RANK="0", LOCAL_RANK="0"),
                          capture_output=True, text=True, timeout=600)
     assert res.returncode != 0 and "needs an MI355X" in res.stderr
+
+
+def test_bench_same_device_flag_and_cpu_topology():
+    """--same-device (N ranks on cuda:0 over gloo: BASELINE config 5's code path inside a one-GPU lease) spawns N ranks as well and does not
+    ask for N GPUs; the CPU baseline reports PHYSICAL cores next to hardware threads"""
+    env = dict(os.environ, BENCH_PRINT_SPAWN="1")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--w", "26", "--htsz", "25"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    cmd = json.loads(res.stdout.strip().splitlines()[-1])
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and "--same-device" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    cores, threads = bench.cpu_topology()
+    assert 1 <= cores <= threads == (os.cpu_count() or 1)
+    pairs = set()
+    phys = core = None
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("physical id"):
+            phys = line.split(":")[1].strip()
+        elif line.startswith("core id"):
+            core = line.split(":")[1].strip()
+            pairs.add((phys, core))
+    if pairs:
+        assert cores == len(pairs)
