@@ -197,7 +197,7 @@ static int ext_check(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
 // upper estimate of the entries that will not fit their line (Poisson loads), with slack
 static uint64_t ext_list_capacity(uint64_t w, uint32_t htsz, uint32_t layout)
 {
-    const unsigned cap_line = layout == BSGS_TABLE_LINES128_LIST ? 31 : 15;
+    const unsigned cap_line = layout == BSGS_TABLE_LINES128_LIST ? 30 : 14;      // the last word of a full line is the bound of its overflow entries (ext_scatter_kernel)
     const double buckets = (double)(1ull << htsz);
     return std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / buckets, cap_line, buckets)) + (1u << 20));
 }
@@ -270,6 +270,22 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
     if (h[1] > ovf_cap) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries, capacity %llu", h[1], (unsigned long long)ovf_cap);
     (void)hipFree(chainb.p); chainb.p = nullptr;
     (void)hipFree(keys.p); keys.p = nullptr;
+    if (h[1]) {
+        // OVERFLOW BOUND (giant_kernel.hip.h): sort the overflow list by (bucket, hash), then per bucket keep the smallest hashes in the line
+        // and put the smallest of the others into the line's last word
+        DevBuf sorted, tmp;
+        HIPCHK(sorted.alloc(h[1] * 8));
+        size_t tmp_bytes = 0;
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, 32u + htsz, d->stream));
+        HIPCHK(tmp.alloc(tmp_bytes));
+        HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, 32u + htsz, d->stream));
+        HIPCHK(hipMemcpyAsync(ovf, sorted.p, h[1] * 8, hipMemcpyDeviceToDevice, d->stream));
+        const int rblocks = (int)std::min<uint64_t>((h[1] + 255) / 256, 1u << 16);
+        if (lplog == 2) hipLaunchKernelGGL(ext_refine_kernel<2>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1]);
+        else            hipLaunchKernelGGL(ext_refine_kernel<3>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1]);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(d->stream));
+    }
     int rc = bsgs_ovf_fill(d, ovf, h[1], ovf_table, ovf_slots);
     if (rc) return rc;
     *ovf_n = ovf_slots; *overflow_buckets = h[0];
