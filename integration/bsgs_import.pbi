@@ -83,4 +83,11 @@ CompilerEndIf
   bsgs_tiles_per_launch(dev.i, *n)                                   ; how many tiles one call of bsgs_run_walk should carry (the batch GetJob dispenses)
   bsgs_chain_placement(dev.i, *info5, *grade2)                       ; diagnostics: where the engine put its scratch (nothing to do for the host)
   bsgs_tune_placement(dev.i, candidates.l, *ms_out, *chosen2, *final_ms)   ; optional: choose the buffer placement by timed launches as well
+  bsgs_prepare(dev.i)                                                ; round 3: allocate the scratch at start-up (like cuMemAlloc_v2 before the search loop, :2251)
+  bsgs_build_baby_table_ext(dev.i, w.q, htsz.l, layout.l)            ; -w above 32: table built in GPU memory (layout 4 = 64-byte lines + overflow set); INTEGRATION.md
+  bsgs_ext_overflow_capacity(w.q, htsz.l, layout.l, *ovf_cap)        ; multi-process hosts: size of the overflow set of such a table ...
+  bsgs_alloc_table_ext_recv(dev.i, w.q, htsz.l, layout.l, *lines, *ovf, *ovf_cap)        ; ... receive buffers from the engine's allocator (reserved memory group above 40 GiB)
+  bsgs_build_baby_table_ext_device(dev.i, w.q, htsz.l, layout.l, lines.i, ovf.i, ovf_cap.q, *ovf_n, *overflow_buckets)   ; ... rank 0 builds into its pair
+  bsgs_install_table_ext_device(dev.i, lines.i, ovf.i, ovf_n.q, overflow_buckets.q, w.q, htsz.l, layout.l)                ; ... every rank installs its pair after the broadcast
+  bsgs_compat_stats_ex(*launches, *served, *batches, *wasted_tiles)  ; route A: how the adaptive predicted batches fared
 EndImport
