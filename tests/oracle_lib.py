@@ -102,6 +102,7 @@ def lib():
             "o_fast_unpack_g2": (None, [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, u8p]),
             "o_fast_tile_slice_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p, C.c_uint64, C.c_int,
                                                C.POINTER(C.c_uint64)]),
+            "o_fast_tile_slice_keys_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, u8p]),
             "o_tile_xs": (C.c_int, [ppt, ppt, C.c_uint32, pfe, pfe, pfe]),
             "o_job_init": (C.c_int, [C.POINTER(Job), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.c_uint32, pfe, ppt, pfe]),
@@ -222,6 +223,19 @@ def tile_slice_keys(P, g2buf, t, b, p, tid0, tid1, flags=0):
     keys = np.zeros((tid1 - tid0, p, 2), dtype=np.uint64)
     ptr = g2buf.ctypes.data_as(C.c_void_p) if hasattr(g2buf, "ctypes") else C.cast(g2buf, C.c_void_p)
     lib().o_tile_ref_slice_keys(C.byref(Pt.from_ints(*P)), ptr, t, b, p, flags, tid0, tid1, keys.ctypes.data_as(C.c_void_p))
+    return keys
+
+
+def fast_tile_slice_keys(P, g2buf, t, b, p, tid0, tid1, nthreads=1):
+    """every probed 64-bit key of the reference threads [tid0, tid1) by the fast CPU implementation: uint64[(tid1-tid0), p, 2]"""
+    import numpy as np
+    ptr = lambda x: x.ctypes.data_as(C.c_void_p) if hasattr(x, "ctypes") else C.cast(x, C.c_void_p)  # noqa: E731
+    count = (tid1 - tid0) * p
+    plain = np.empty(8 * count, dtype=np.uint64)
+    lib().o_fast_unpack_g2(ptr(g2buf), t, b, p, tid0 * p, count, plain.ctypes.data_as(C.c_void_p))
+    keys = np.zeros((tid1 - tid0, p, 2), dtype=np.uint64)
+    lib().o_fast_tile_slice_keys_mt(C.byref(Pt.from_ints(*P)), plain.ctypes.data_as(C.c_void_p), tid0 * p, p, tid0, tid1, nthreads,
+                                    keys.ctypes.data_as(C.c_void_p))
     return keys
 
 

@@ -94,3 +94,16 @@ def test_random_against_python_ints():
     for a in (0, 1, P - 1, 2**256 - 1, 2**255, P + 5):      # unreduced operands still reduce correctly
         for b in (1, P - 1, 2**256 - 1, 0x1000003D1):
             assert O.fe_op("o_mulModX64", a, b) == a * b % P
+
+
+def test_fast_cpu_keys_equal_the_literal_port():
+    """oracle/cpu_fast.c (the multi-threaded CPU implementation the whole-tile GPU test takes its 2^25 keys from) lists, key by key, what the
+    literal restatement of the reference kernel lists (o_tile_ref_slice_keys): a random tile and an equal-x tile (x(2P) slot)"""
+    import numpy as np
+    import oracle_lib as O
+    t, b, p, w = 8, 4, 16, 1 << 12
+    g2 = np.frombuffer(O.build_g2(t, b, p, w), dtype=np.uint8)
+    for P in (O.pt_mul(987654321987654321), O.g2_unpack(g2.tobytes(), t, b, p, 77), O.pt_neg(O.g2_unpack(g2.tobytes(), t, b, p, 300))):
+        a = O.tile_slice_keys(P, g2, t, b, p, 0, t * b)
+        f = O.fast_tile_slice_keys(P, g2, t, b, p, 0, t * b, 4)
+        assert a.shape == f.shape == (t * b, p, 2) and (a == f).all()
