@@ -223,14 +223,15 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
 // one product per two giants); `full` = the caller is a generator kernel that needs the per-giant chain of one tile
 static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
 {
-    const bool halfchain = !full && (d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);   // = the dispatch of giant_pair2_kernel
+    const bool halfchain = !full && (d->variant == 10 || d->variant == 11 || d->variant == 13) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);   // = the dispatch of giant_pair2_kernel
     // the tiles' scratch areas are 2^28 bytes apart at the usual geometry; tiles of a launch touch the same offsets at about the
     // same time, so a pad breaks the power-of-two stride between them (BSGS_CHAIN_PAD bytes, pair-batched kernel only)
     static const uint64_t pad_env = getenv("BSGS_CHAIN_PAD") ? strtoull(getenv("BSGS_CHAIN_PAD"), nullptr, 10) : 0;
     d->chain_pad = halfchain ? (uint32_t)(pad_env / 16) : 0;
     // the pair-batched kernel's scratch is [tile][block][pair][2][block size]: whole blocks (the tail block is padded)
     const uint64_t threads_padded = ((uint64_t)d->Ti + d->block_size - 1) / d->block_size * d->block_size;
-    const uint64_t per_tile = (halfchain ? threads_padded * d->pi * 16 : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16;
+    const bool quad = halfchain && d->variant == 13 && (d->pi & 3u) == 0;                                          // one stored product per four giants: 8 bytes per giant
+    const uint64_t per_tile = (halfchain ? threads_padded * d->pi * (quad ? 8 : 16) : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16;
     const uint64_t per_stream = per_tile * tiles;
     const uint64_t bytes = per_stream * (d->nstreams == 2 ? 2 : 1);                 // one scratch per stream
     static const bool pieces_on = !(getenv("BSGS_CHAIN_PIECES") && atoi(getenv("BSGS_CHAIN_PIECES")) == 0);
@@ -286,8 +287,8 @@ static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
     const uint64_t want = (uint64_t)d->prop.multiProcessorCount * (d->nstreams == 2 ? 512 : 3072);
     uint64_t n = std::min<uint64_t>(std::max<uint64_t>((want + d->Ti - 1) / d->Ti, 1), BSGS_TILES_PER_LAUNCH);
     size_t fr = 0, tot = 0;
-    const bool halfchain = (d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
-    const uint64_t per_giant = halfchain ? 16 : 32;             // as ensure_chain sizes the scratch
+    const bool halfchain = (d->variant == 10 || d->variant == 11 || d->variant == 13) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
+    const uint64_t per_giant = halfchain ? ((d->variant == 13 && (d->pi & 3u) == 0) ? 8 : 16) : 32;             // as ensure_chain sizes the scratch
     if (d->nstreams == 1 && bsgs_mem_available(&fr, &tot) == hipSuccess) {
         fr += d->chain_bytes + d->group0_reserve.size() * d->group0_piece_bytes;     // what is already ours (scratch, reserve) counts as available
         for (uint64_t mult = 4; mult > 1; mult /= 2)
@@ -563,18 +564,30 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
         HIPCHK(hipGetLastError());
         return BSGS_OK;
     }
-    if ((d->variant == 10 || d->variant == 11) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+    if (d->variant == 13 && (d->pi & 3u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+        // QUAD: one stored product per four giants, one probe in flight per wave (giant_kernel.hip.h); same LDS footprint as the pair kernel
+        const bool l128 = d->layout == BSGS_TABLE_LINES128;
+        const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048);
+        const bool dbg = d->debug_flags != 0 || d->phase_probe;
+        if (l128) { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<3, true, false, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<3, false, false, true>), grid, block, lds, st, A); }
+        else      { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<2, true, false, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<2, false, false, true>), grid, block, lds, st, A); }
+        HIPCHK(hipGetLastError());
+        d->last_kernel = l128 ? (dbg ? "giant_pair2_kernel<3, true, false, true>" : "giant_pair2_kernel<3, false, false, true>")
+                              : (dbg ? "giant_pair2_kernel<2, true, false, true>" : "giant_pair2_kernel<2, false, false, true>");
+        return BSGS_OK;
+    }
+    if ((d->variant == 10 || d->variant == 11 || d->variant == 13) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         const bool l128 = d->layout == BSGS_TABLE_LINES128;
         const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048);           // probe slots + S stash per wave: 4 blocks fill the 160 KiB of a CU exactly
         const bool dbg = d->debug_flags != 0 || d->phase_probe;
         if (l128) { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<3, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<3, false>), grid, block, lds, st, A); }
         else      { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<2, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<2, false>), grid, block, lds, st, A); }
         HIPCHK(hipGetLastError());
-        d->last_kernel = l128 ? (dbg ? "giant_pair2_kernel<3, true, false>" : "giant_pair2_kernel<3, false, false>")
-                              : (dbg ? "giant_pair2_kernel<2, true, false>" : "giant_pair2_kernel<2, false, false>");
+        d->last_kernel = l128 ? (dbg ? "giant_pair2_kernel<3, true, false, false>" : "giant_pair2_kernel<3, false, false, false>")
+                              : (dbg ? "giant_pair2_kernel<2, true, false, false>" : "giant_pair2_kernel<2, false, false, false>");
         return BSGS_OK;
     }
-    if ((d->variant >= 9 && d->variant <= 11) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+    if (((d->variant >= 9 && d->variant <= 11) || d->variant == 13) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         const bool l128 = d->layout == BSGS_TABLE_LINES128;
         const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
         const bool dbg = d->debug_flags != 0 || d->phase_probe;
@@ -796,7 +809,7 @@ extern "C" int bsgs_prepare(bsgs_dev *d)
     if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
     if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
     HIPCHK(hipSetDevice(d->id));
-    if ((d->variant >= 3 && d->variant <= 5) || d->variant == 11) return BSGS_OK;      // streamed / pooled variants keep their own scratch
+    if ((d->variant >= 3 && d->variant <= 5) || d->variant == 11) return BSGS_OK;      // streamed / pooled variants keep their own scratch (13, 10, ... : the chain scratch below)
     int rc = ensure_chain(d, auto_tiles_per_launch(d));
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(d->stream));
@@ -1117,7 +1130,7 @@ extern "C" int bsgs_run_digest(bsgs_dev *d, const uint8_t *centres, uint32_t nti
     hipError_t e = hipMemsetAsync(d->digest, 0, bytes, d->stream);
     const unsigned saved_flags = d->debug_flags;
     const int saved_variant = d->variant;
-    d->debug_flags = 8u; d->variant = 10; d->phase_probe = true;
+    d->debug_flags = 8u; d->variant = 13; d->phase_probe = true;       // the default kernel (quad chain; pair chain for odd batch lengths), instrumented instantiation
     int rc = e == hipSuccess ? bsgs_run(d, centres, ntiles, hits, max_hits, nhits, nullptr) : fail(BSGS_ERR_HIP, "memset: %s", hipGetErrorString(e));
     d->debug_flags = saved_flags; d->variant = saved_variant; d->phase_probe = false;
     if (rc == BSGS_OK || rc == BSGS_ERR_OVERFLOW) {
@@ -1146,7 +1159,7 @@ extern "C" int bsgs_debug_xcd_profile(bsgs_dev *d, uint64_t first_tile, uint32_t
     const unsigned saved_flags = d->debug_flags;
     const int saved_variant = d->variant;
     const uint32_t saved_tpl = d->tiles_per_launch;
-    d->debug_flags = 16u; d->variant = 10; d->phase_probe = true; d->tiles_per_launch = ntiles;
+    d->debug_flags = 16u; d->variant = 13; d->phase_probe = true; d->tiles_per_launch = ntiles;
     // launch_tiles offsets the digest pointer by seq * Ti * 2: one launch, seq = 0
     int rc = e == hipSuccess ? bsgs_run_walk(d, first_tile, ntiles, nullptr, 0, nullptr, launch_ms) : fail(BSGS_ERR_HIP, "memset");
     d->debug_flags = saved_flags; d->variant = saved_variant; d->phase_probe = false; d->tiles_per_launch = saved_tpl;

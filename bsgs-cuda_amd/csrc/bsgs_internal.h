@@ -64,7 +64,8 @@ struct bsgs_dev {
     uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
     uint32_t auto_tpl = 0;                 // the automatic choice, made once the giants and the table are resident (memory permitting: 4x)
     uint64_t launches = 0;
-    int variant = 10;           // BSGS_KERNEL_VARIANT (all bit-identical): per-tile kernels 0 synchronous probes, 1 pipelined probes,
+    int variant = 13;           // BSGS_KERNEL_VARIANT (all bit-identical): 13 (default) = 10 with ONE stored product per FOUR giants and one probe in flight per wave
+                                // (falls back to 10 when the engine's batch length is not a multiple of 4); per-tile kernels 0 synchronous probes, 1 pipelined probes,
                                 // 2 early / 7 late prefetch, 8 = 7 + LDS-staged probe, 9 = both probes LDS-staged, 6 pair-batched chain,
                                 // 10 = 9 + pair-batched chain (default; falls back to 9 for an odd chain length), 11 = 10 as ONE launch
                                 // per queue with pooled chain scratch (slower sustained: DESIGN.md 8); streamed ping-pong

@@ -229,8 +229,9 @@ def test_hit_lists_of_two_independent_kernels_agree_under_load():
         cur = ecpy.add(cur, stride_pt)
     centres[5] = ecpy.mul((777 * 2 * w + 31337) % N)            # planted: code 1 at giant 776
     centres[143] = ecpy.mul((N - (maxnonce * 2 * w) + 99) % N)  # planted: code 2 at the last giant
-    # the default kernel's scratch lies in pieces of 16 tiles: a planted hit in the first and the last tile of every piece
-    edge_tiles = [t for k in range(9) for t in (16 * k, 16 * k + 15) if t not in (5, 143)]
+    # the default kernel's scratch lies in pieces of 32 tiles (8 bytes per giant: one stored product per four giants): a planted hit in the first and
+    # the last tile of every piece, and around the former 16-tile boundaries
+    edge_tiles = sorted({t for k in range(5) for t in (32 * k, min(32 * k + 31, 142))} | {15, 16, 47, 48, 111, 112} - {5, 143})
     for t in edge_tiles:
         centres[t] = ecpy.mul(((t + 100) * 2 * w + 1000 + t) % N)     # code 1 at giant t + 99
     res = {}
@@ -240,15 +241,15 @@ def test_hit_lists_of_two_independent_kernels_agree_under_load():
         assert n == len(hits)
         res[layout] = hits
         if layout == pybsgs.TABLE_LINES64:
-            # the default kernel's scratch (sized for a full launch of 192 tiles: 48 GiB) lies in pieces of 16 tiles graded against the 16 GiB of bucket
+            # the default kernel's scratch (sized for a full launch of 192 tiles: 24 GiB) lies in pieces of 32 tiles graded against the 16 GiB of bucket
             # lines -- and the hit lists equal those of the one-buffer CSR kernel below
             cp = dev.chain_placement()
-            assert cp["pieces"] in (9, 12) and cp["tiles_per_piece"] == 16 and cp["handed_back"] == cp["graded"] - cp["pieces"] >= 0
+            assert cp["pieces"] in (5, 6) and cp["tiles_per_piece"] == 32 and cp["handed_back"] == cp["graded"] - cp["pieces"] >= 0
             assert cp["best_grade_G_per_s"] >= cp["worst_kept_grade_G_per_s"] > 0 and not cp["from_reserved_group"]
     assert dev.chain_placement()["pieces"] == 0                  # the per-giant kernel took one buffer
-    # launches of 40 tiles: three pieces, the last one half used, four launches for the 144 tiles -- the same hit list
+    # launches of 72 tiles: three pieces, the last one a quarter used, two launches for the 144 tiles -- the same hit list
     dev.upload_htgpu_device(img.data_ptr(), 1 << htsz, w, pybsgs.TABLE_LINES64)
-    dev.set_tiles_per_launch(40)
+    dev.set_tiles_per_launch(72)
     hits40, n40, _ = dev.run(centres, 65536)
     assert dev.chain_placement()["pieces"] == 3 and hits40 == res[pybsgs.TABLE_LINES64]
     dev.set_tiles_per_launch(0)

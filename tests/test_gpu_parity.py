@@ -339,7 +339,7 @@ def test_cuda_compat_layer_runs_a_tile(small_fx):
     assert L.cuCtxDestroy_v2(ctx) == 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
 @pytest.mark.parametrize("streams", [1, 2])
 def test_all_kernel_variants_agree_with_oracle(O, small_fx, variant, streams):
     """every kernel variant (per-tile 0-2, streamed 3-5; one or two HIP streams) returns the oracle's hit lists:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction budget of the hot loop of giant_pair2_kernel<2, false, false> (the default tile kernel).
+"""Static instruction budget of the hot loop of giant_pair2_kernel<2, false, false, true> (the default tile kernel: quad chain; ISA_KERNEL=..ELb0EEv8TileArgs for the pair chain).
 
   tools/isa_budget.py [out.json]      (needs hipcc; cross-compiles for gfx950, no GPU)
 
@@ -24,7 +24,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = os.environ.get("ISA_KERNEL", "_Z18giant_pair2_kernelILi2ELb0ELb0EEv8TileArgs")
+KERNEL = os.environ.get("ISA_KERNEL", "_Z18giant_pair2_kernelILi2ELb0ELb0ELb1EEv8TileArgs")
 COST = {"mad64": 4.2, "carry": 4.1, "plain": 2.3}
 
 
@@ -104,14 +104,15 @@ def main():
         for n, v in c.items():
             if n.startswith("v_"):
                 d[group(n)] += v
-    res = {"kernel": "giant_pair2_kernel<2, false, false>", "vgprs": int(vgpr.group(1)) if vgpr else None,
-           "loop": "one iteration = one pair of giants = 4 giant steps (two x coordinates per giant)",
+    res = {"kernel": "giant_pair2_kernel<2, false, false, true>" if KERNEL.endswith("ELb1EEv8TileArgs") else "giant_pair2_kernel<2, false, false, false>", "vgprs": int(vgpr.group(1)) if vgpr else None,
+           "loop": "one iteration = four giants = 8 giant steps (quad chain) or one pair of giants = 4 giant steps (pair chain); two x coordinates per giant",
            "cost_cycles_per_wave_instruction": COST, "classes": {}}
     for kind, d in classes.items():
         d["issue_cycles"] = round(sum(d[g] * COST[g] for g in COST), 1)
         res["classes"][kind] = d
     main_path = [res["classes"][k] for k in ("M", "S", "glue") if k in res["classes"]]
-    per_step = {g: sum(d[g] for d in main_path) / 4.0 for g in ("valu", "mad64", "carry", "plain")}
+    steps_per_iteration = 8.0 if KERNEL.endswith("ELb1EEv8TileArgs") else 4.0      # quad chain: one iteration = four giants; pair chain: two
+    per_step = {g: sum(d[g] for d in main_path) / steps_per_iteration for g in ("valu", "mad64", "carry", "plain")}
     res["probe_loop_per_giant_step"] = {k: round(v, 1) for k, v in per_step.items()}
     res["probe_loop_per_giant_step"]["issue_cycles"] = round(sum(per_step[g] * COST[g] for g in COST), 1)
     m = res["classes"].get("M")

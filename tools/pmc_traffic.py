@@ -19,12 +19,17 @@ def rows(path):
     return list(csv.DictReader(open(path)))
 
 
+import re
+PROD = re.compile(r"giant_pair2_kernel<\d, false, false(, (true|false))?>")      # production instantiations (PHASE_PROBE = false, POOL = false)
+
+
 def pick(d, counter, kernel_sub, exclude=None):
     for name in sorted(os.listdir(d)):
         if not name.startswith("rocprofv3_pmc_"):
             continue
         for r in rows(os.path.join(d, name)):
-            if r["counter"] == counter and kernel_sub in r["kernel"] and not (exclude and exclude in r["kernel"]):
+            ok = PROD.search(r["kernel"]) if kernel_sub is PROD else kernel_sub in r["kernel"]
+            if r["counter"] == counter and ok and not (exclude and exclude in r["kernel"]):
                 return float(r["mean"]), int(r["dispatches"]), r["kernel"]
     return None, 0, None
 
@@ -32,7 +37,7 @@ def pick(d, counter, kernel_sub, exclude=None):
 def main():
     d, out = sys.argv[1], sys.argv[2]
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 48 << 25           # the default launch: 48 tiles of 2^25 giant steps
-    prod = ", false>"                                   # production instantiation (PHASE_PROBE = false)
+    prod = PROD
     fetch, nf, kname = pick(d, "FETCH_SIZE", "giant_", None)
     fetch, nf, kname = pick(d, "FETCH_SIZE", prod)
     write, _, _ = pick(d, "WRITE_SIZE", prod)
@@ -67,7 +72,7 @@ def main():
         bj = json.loads(line)
         wl = bj["config"]["workload"].split()
         cfg = {"t": int(wl[1]), "b": int(wl[3]), "p": int(wl[5]), "w": float(wl[7]), "htsz": int(wl[9].rstrip(":")),
-               "layout": bj["config"]["table_layout"], "variant": os.environ.get("BSGS_KERNEL_VARIANT", "10")}
+               "layout": bj["config"]["table_layout"], "variant": os.environ.get("BSGS_KERNEL_VARIANT", "13")}
         res["config"] = cfg
         res["steps_per_launch"] = steps = int(bj["roofline"]["algorithmic_bytes_per_launch"] / 64)
         for k in ("fetch", "write"):
