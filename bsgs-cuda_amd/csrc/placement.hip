@@ -210,9 +210,14 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
     const size_t extra = can_grade ? 24 + (getenv("BSGS_GRADE_MORE") ? 24 : 0) : 0;                  // at most this many more than needed (the slow class holds 16...22 granules of 4 GiB)
     float best = 0.f;
     auto good = [&]() { size_t n = 0; for (const Cand &c : cands) n += c.g >= 0.98f * best; return n; };      // pieces sharing a group with the lines grade 6-10 % lower, straddlers 2-3 %
+    // "enough pieces within 2 % of the best seen" only means something once BOTH classes were seen: consecutive allocations tend to come from one
+    // memory group, and with the 6 pieces a launch needs since round 3 (8 bytes per giant) the first six were sometimes all in the bucket lines'
+    // group -- uniformly bad, all "within 2 % of the best", 175 ms per launch instead of 160 (profiles/r04f_*).  So the draw goes on until some piece
+    // grades at least 5 % below the best (the best is then the far class), or 12 more than needed have been looked at (one class is all there is).
+    auto two_classes = [&]() { for (const Cand &c : cands) if (c.g <= 0.95f * best) return true; return false; };
     while (cands.size() < npieces + extra) {
         static const size_t grade_more = getenv("BSGS_GRADE_MORE") ? (size_t)atoi(getenv("BSGS_GRADE_MORE")) : 0;     // diagnostics: look at this many extra pieces
-        if (cands.size() >= npieces + grade_more && (!can_grade || good() >= npieces)) break;
+        if (cands.size() >= npieces + grade_more && (!can_grade || (good() >= npieces && (two_classes() || cands.size() >= npieces + 12)))) break;
         size_t fr = 0, tot = 0;
         if (cands.size() >= npieces && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece_bytes + (6ull << 30))) break;   // leave room for the rest of the engine
         void *p = nullptr;
