@@ -281,7 +281,7 @@ static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
     if (d->auto_tpl) return d->auto_tpl;
     // One launch = three rounds of resident blocks at least (4 waves per SIMD fill the chip): 48 tiles of 16384 engine threads.
     // A launch boundary (ramp: every resident block in the streaming-bound prefix phase; tail) costs ~1.5 ms, i.e. 3.5 % at 48
-    // tiles (44.7 ms); the centres live in device memory, so nothing but the chain scratch (16 bytes x giants per tile in flight)
+    // tiles (44.7 ms); the centres live in device memory, so nothing but the chain scratch (8 bytes x giants per tile in flight; 16 with the pair chain)
     // limits a launch: measured 36.0 / 37.3 / 37.5 G giant-steps/s at 48 / 96 / 192 tiles (profiles/r02a_ab_tiles_per_launch.log).
     // Take 4x the fill-the-chip figure when that scratch fits in a third of the free memory, else 2x, else 1x.
     const uint64_t want = (uint64_t)d->prop.multiProcessorCount * (d->nstreams == 2 ? 512 : 3072);
