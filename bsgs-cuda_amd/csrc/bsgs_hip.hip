@@ -62,6 +62,7 @@ extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
     if (const char *v = getenv("BSGS_DEBUG_PHASES")) d->debug_flags = (unsigned)atoi(v);     // timing experiments only
     if (const char *v = getenv("BSGS_BLOCK")) { int bsz = atoi(v); if (bsz == 64 || bsz == 128 || bsz == 256) d->block_size = (unsigned)bsz; }
     if (const char *v = getenv("BSGS_STREAMS")) d->nstreams = atoi(v) == 2 ? 2 : 1;     // tuning / A-B only
+    if (const char *v = getenv("BSGS_NARROW_LAUNCHES")) d->narrow_off = atoi(v) == 0;     // A-B only: 0 = every launch with the default batching
     HIPCHK(hipMalloc(&d->hitbuf, hitbuf_bytes(d)));
     HIPCHK(hipHostMalloc(&d->hit_host, hitbuf_bytes(d), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(d->hitbuf, 0, 64, d->stream));
@@ -84,9 +85,15 @@ void bsgs_free_recv(bsgs_dev *d)
     if (d->recv_ovf) (void)hipFree(d->recv_ovf);
     d->recv_lines = d->recv_ovf = nullptr;
 }
+static void free_narrow(bsgs_dev *d)
+{
+    for (auto &b : d->narrow) if (b.g2) (void)hipFree(b.g2);
+    d->narrow.clear();
+}
 static void free_g2(bsgs_dev *d)
 {
     if (d->g2) (void)hipFree(d->g2);
+    free_narrow(d);
     if (d->chain) (void)hipFree(d->chain);
     free_chain_pieces(d);
     if (d->schain) (void)hipFree(d->schain);
@@ -185,6 +192,14 @@ extern "C" int bsgs_set_flags(bsgs_dev *d, uint32_t flags)
     return BSGS_OK;
 }
 // the tile-kernel instantiation the most recent launch used, as rocprofv3 names it (the parity tests assert they ran the SHIPPED one)
+extern "C" int bsgs_debug_last_batching(bsgs_dev *d, uint32_t *threads, uint32_t *giants_per_thread)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (threads) *threads = d->last_Ti;
+    if (giants_per_thread) *giants_per_thread = d->last_pi;
+    return BSGS_OK;
+}
+
 extern "C" int bsgs_debug_last_kernel(bsgs_dev *d, char *buf, int len)
 {
     if (!d || !buf || len <= 0) return fail(BSGS_ERR_ARG, "bad args");
@@ -531,18 +546,54 @@ static int ensure_centres(bsgs_dev *d, uint64_t tiles)
     return BSGS_OK;
 }
 
+// ---- small launches ------------------------------------------------------------------------------------
+// The default batching trades threads for batch length (set_geometry: 16384 threads x 1024 giants at -t 256 -b 256 -p 256) and wins the threads back
+// with many tiles per launch.  A launch of ONE tile -- the reference's own launch pattern (1_9_7File.pb:2442-2459), what route A does whenever the
+// centres cannot be predicted, what bsgs_step is -- then occupies 64 blocks of a 256-CU GPU: 6.5 G giant steps/s.  Any factorisation Ti' x pi' of
+// maxnonce numbers the giants the same way (i = thread * pi' + slot), so such a launch takes a second copy of the giants laid out for shorter
+// batches and more threads: the longest batch (>= 128 giants: below that the Fermat inversion, 270 multiplications per thread, costs more than the
+// occupancy brings) that still gives the launch four blocks per CU.  profiles/r04n_one_tile_launch_batching.log: 1 tile 6.5 -> 25.8 G, 4 tiles 25.3 -> 33.2 G.
+static bool lines_layout(const bsgs_dev *d);
+static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles, int which)
+{
+    if (d->narrow_off || which || d->nstreams != 1 || d->digest || d->debug_flags || d->phase_probe || !lines_layout(d)) return nullptr;
+    if ((d->variant != 10 && d->variant != 13) || (d->pi & 3u)) return nullptr;
+    if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) return nullptr;        // the quirk list is indexed by the default batching
+    const uint64_t target = (uint64_t)d->prop.multiProcessorCount * 1024;                        // four blocks of 256 threads per CU
+    uint32_t pi = d->pi;
+    while ((uint64_t)ntiles * (d->maxnonce / pi) < target && pi / 2 >= 128 && ((pi / 2) & 3u) == 0 &&
+           d->maxnonce / (pi / 2) < (1ull << 31) && (d->maxnonce / (pi / 2)) % d->block_size == 0) pi /= 2;
+    if (pi == d->pi) return nullptr;
+    for (const auto &b : d->narrow) if (b.pi == pi) return &b;
+    // build it: 64 bytes per giant once more.  Not at the expense of anything else: only while twice that much (and 2 GiB) is free
+    size_t fr = 0, tot = 0;
+    const uint64_t bytes = d->maxnonce * 64;
+    if (bsgs_mem_available(&fr, &tot) != hipSuccess || fr < 2 * bytes + (2ull << 30)) { d->narrow_off = true; return nullptr; }
+    bsgs_dev::Batching nb;
+    nb.pi = pi; nb.Ti = (uint32_t)(d->maxnonce / pi);
+    if (hipMalloc(&nb.g2, bytes) != hipSuccess) { (void)hipGetLastError(); d->narrow_off = true; return nullptr; }
+    const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
+    hipLaunchKernelGGL(g2_rebatch_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)d->g2, d->Ti, d->pi, nb.g2, nb.Ti, nb.pi, d->maxnonce);
+    if (hipGetLastError() != hipSuccess) { (void)hipFree(nb.g2); d->narrow_off = true; return nullptr; }
+    d->narrow.push_back(nb);
+    return &d->narrow.back();
+}
+
 static int quirk_prepare(bsgs_dev *d);
 static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uint32_t seq, int which)
 {
     TileArgs A;
     hipStream_t st = which ? d->stream2 : d->stream;
+    const bsgs_dev::Batching *nb = pick_batching(d, ntiles, which);
+    const uint32_t Ti = nb ? nb->Ti : d->Ti, pi = nb ? nb->pi : d->pi;
+    d->last_Ti = Ti; d->last_pi = pi;
     d->last_kernel = "another variant (BSGS_KERNEL_VARIANT / CSR layout / odd chain length)";
-    A.g2 = d->g2; A.chain = d->chain + (which ? d->chain_stride : 0); A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
-    A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
+    A.g2 = nb ? nb->g2 : d->g2; A.chain = d->chain + (which ? d->chain_stride : 0); A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
+    A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = pi; A.T = Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;
     A.centres_dev = centres_dev; A.pool = nullptr; A.pool_cap = 0; A.pool_stride = 0;
-    A.digest = d->digest ? d->digest + (uint64_t)seq * d->Ti * 2 : nullptr;
+    A.digest = d->digest ? d->digest + (uint64_t)seq * Ti * 2 : nullptr;
     A.chain_pad = d->chain_pad; A.chain_mode = 0;
     for (int k = 0; k < BSGS_CHAIN_PIECES_MAX; k++) A.chain_piece[k] = nullptr;
     if (!d->chain_pieces.empty()) {                        // pair-batched kernel, one stream (ensure_chain)
@@ -557,14 +608,14 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
                            (const u32 *)d->quirk_list, (u32)d->quirk_host.size());
         HIPCHK(hipGetLastError());
     }
-    const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
+    const dim3 grid((unsigned)(((Ti + bs - 1) / bs) * ntiles)), block(bs);
     if (d->variant == 6 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         if (d->layout == BSGS_TABLE_LINES64) hipLaunchKernelGGL(giant_pair_kernel<2>, grid, block, 0, st, A);
         else                                 hipLaunchKernelGGL(giant_pair_kernel<3>, grid, block, 0, st, A);
         HIPCHK(hipGetLastError());
         return BSGS_OK;
     }
-    if (d->variant == 13 && (d->pi & 3u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
+    if (d->variant == 13 && (pi & 3u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
         // QUAD: one stored product per four giants, one probe in flight per wave (giant_kernel.hip.h); same LDS footprint as the pair kernel
         const bool l128 = d->layout == BSGS_TABLE_LINES128;
         const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048);

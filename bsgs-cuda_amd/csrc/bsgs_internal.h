@@ -48,6 +48,13 @@ struct bsgs_dev {
     std::vector<void *> pending_dev, pending_pinned;   // per-enqueue centre buffers, released by bsgs_collect
     // buffers
     u32x4 *g2 = nullptr;        // [p][4][T]
+    // The same giants dealt to MORE threads with shorter batches (giant i = thread * pi + slot for every factorisation Ti * pi = maxnonce, so hit
+    // indices do not change): built on demand for launches of so few tiles that the default batching leaves most of the GPU idle -- the reference's own
+    // pattern is ONE tile per launch (1_9_7File.pb:2442-2459).  `narrow_off`: BSGS_NARROW_LAUNCHES=0 (A-B), or a layout that did not fit once.
+    struct Batching { uint32_t Ti = 0, pi = 0; u32x4 *g2 = nullptr; };
+    std::vector<Batching> narrow;
+    bool narrow_off = false;
+    uint32_t last_Ti = 0, last_pi = 0;     // batching of the last tile launch (bsgs_debug_last_batching)
     u32x4 *chain = nullptr;     // [stream][tile][p][2][T]
     u32 *csr = nullptr;         // htGPU image
     bool csr_owned = true;
