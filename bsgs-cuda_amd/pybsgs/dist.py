@@ -7,13 +7,31 @@ import torch
 import torch.distributed as td
 
 
+# BSGS_DIST_FORCE=1: a single process still creates the process group and goes through every collective (a one-rank RCCL communicator): the
+# multi-rank code path of bench.py -- RCCL next to the engine in one process, broadcasts into engine-owned memory -- inside a one-GPU lease
+FORCE = os.environ.get("BSGS_DIST_FORCE") == "1"
+
+
 def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def _alone():
+    return not (td.is_available() and td.is_initialized()) or (td.get_world_size() == 1 and not FORCE)
+
+
 def init(backend, device=None):
     rank, local_rank, world = env_world()
-    if world > 1 and not td.is_initialized():
+    if world == 1 and FORCE and not td.is_initialized():
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if (world > 1 or FORCE) and not td.is_initialized():
         if backend == "nccl":
             td.init_process_group("nccl", device_id=device)
         else:
@@ -30,7 +48,7 @@ def broadcast_table(img, src=0):
     """start-up broadcast of the htGPU image (a torch tensor on the rank's device); returns seconds spent.  RCCL moves device memory
     directly; on gloo (CPU tests; bench.py --same-device: N ranks on ONE GPU) device tensors are staged through host memory in pieces."""
     import time
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if _alone():
         return 0.0
     if img.is_cuda:
         torch.cuda.synchronize()
@@ -66,7 +84,7 @@ def wrap_device_memory(ptr, nbytes, device):
 
 def gather_objects(obj):
     """every rank's picklable object, in rank order, on every rank"""
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if _alone():
         return [obj]
     out = [None] * td.get_world_size()
     td.all_gather_object(out, obj)
@@ -74,7 +92,7 @@ def gather_objects(obj):
 
 
 def barrier(cuda=True):
-    if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+    if not _alone():
         td.barrier()
     if cuda and torch.cuda.is_available():
         torch.cuda.synchronize()
@@ -82,7 +100,7 @@ def barrier(cuda=True):
 
 def reduce_max(values, device="cpu"):
     """max over ranks of a list of floats (wall time, kernel time)"""
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if _alone():
         return list(values)
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -90,7 +108,7 @@ def reduce_max(values, device="cpu"):
 
 
 def reduce_sum_int(value, device="cpu"):
-    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+    if _alone():
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     td.all_reduce(t, op=td.ReduceOp.SUM)
