@@ -121,8 +121,8 @@ def main():
     s_ = res["classes"].get("S")
     if s_:
         res["one_low64_squaring"] = {g: round(s_[g] / s_["blocks"], 1) for g in ("valu", "mad64", "carry", "plain")}
-    res["note"] = ("outside this loop every giant also costs one prefix-product multiplication + one field addition (phase 1) and 270/1024 of a "
-                   "Fermat inversion: + ~0.63 multiplications per giant step; the PMC total (profiles/*_pmc_traffic.json) covers everything")
+    res["note"] = ("outside this loop every giant also costs one prefix-product multiplication + one field addition (phase 1) and 70/1024 of a "
+                   "Fermat inversion (one per block of four waves): + ~0.53 multiplications per giant step; the PMC total (profiles/*_pmc_traffic.json) covers everything")
     txt = json.dumps(res, indent=1)
     if out:
         open(out, "w").write(txt)
