@@ -289,7 +289,7 @@ size_t MiniBsgs::lookup(uint64_t x64) const
 void MiniBsgs::build(uint64_t w, unsigned threads)
 {
     unsigned lw = 0; while ((1ull << lw) < w) lw++;
-    mb = std::min(22u, std::max(8u, lw / 2 + 5));
+    mb = std::min(24u, std::max(8u, lw / 2 + 7));          // 2^24 stored multiples at -w 34: 2 x 1024 batched additions (1 ms) per reported hit; 2^22 (round 2): 4 ms
     const uint64_t M = 1ull << mb;
     baby.resize(M);
     Q = hs::point_mul(hs::G, hs::fe_from_u64(M));

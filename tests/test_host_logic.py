@@ -80,7 +80,7 @@ def test_table_free_resolver():
     w = 1 << 20
     ms = [1, 77, w, w - 1, 524289, (1 << 15) + 1, N - 1, N - 77, N - w, w + 1, w + 5, 2 * w, N - w - 1, 0x123456789ABCDEF]
     out = selftest("minibsgs", w, *["%x" % m for m in ms])
-    assert out[0] == ["minibsgs_bits", "15"]
+    assert out[0] == ["minibsgs_bits", "17"]            # lw / 2 + 7 stored-multiple bits (24 at -w 34)
     for m, o in zip(ms, out[1:]):
         expect = sorted({b for b in (m, N - m) if 1 <= b <= w})
         assert [int(v) for v in o[2:]] == expect, hex(m)
