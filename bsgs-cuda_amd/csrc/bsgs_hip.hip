@@ -571,7 +571,7 @@ static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles, int
     if (bsgs_mem_available(&fr, &tot) != hipSuccess || fr < 2 * bytes + (2ull << 30)) { d->narrow_off = true; return nullptr; }
     bsgs_dev::Batching nb;
     nb.pi = pi; nb.Ti = (uint32_t)(d->maxnonce / pi);
-    if (hipMalloc(&nb.g2, bytes) != hipSuccess) { (void)hipGetLastError(); d->narrow_off = true; return nullptr; }
+    if (bsgs_big_malloc(&nb.g2, bytes) != hipSuccess) { (void)hipGetLastError(); d->narrow_off = true; return nullptr; }     // like d->g2
     const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
     hipLaunchKernelGGL(g2_rebatch_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)d->g2, d->Ti, d->pi, nb.g2, nb.Ti, nb.pi, d->maxnonce);
     if (hipGetLastError() != hipSuccess) { (void)hipFree(nb.g2); d->narrow_off = true; return nullptr; }
