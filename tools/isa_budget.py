@@ -39,7 +39,7 @@ def group(mn):
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else None
     asm = "/tmp/bsgs_isa_budget.s"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only", "-o", asm,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", *os.environ.get("ISA_DEFS", "").split(), "-S", "--cuda-device-only", "-o", asm,
                            os.path.join(ROOT, "bsgs-cuda_amd", "csrc", "bsgs_hip.hip")], stderr=subprocess.DEVNULL)
     text = open(asm).read()
     lines = text.split("\n")
