@@ -554,15 +554,28 @@ static int ensure_centres(bsgs_dev *d, uint64_t tiles)
 // batches and more threads: the longest batch (>= 128 giants: below that the Fermat inversion, 270 multiplications per thread, costs more than the
 // occupancy brings) that still gives the launch four blocks per CU.  profiles/r04n_one_tile_launch_batching.log: 1 tile 6.5 -> 25.8 G, 4 tiles 25.3 -> 33.2 G.
 static bool lines_layout(const bsgs_dev *d);
+// the rule itself (no device needed: tests/test_host_logic.py drives it through bsgs_debug_narrow_batching)
+static uint32_t narrow_pi(uint64_t maxnonce, uint32_t pi, uint32_t ntiles, uint32_t cus, uint32_t block)
+{
+    const uint64_t target = (uint64_t)cus * 1024;                                                // four blocks of 256 threads per CU
+    if (!pi || !block || (pi & 3u) || maxnonce % pi) return pi;
+    while ((uint64_t)ntiles * (maxnonce / pi) < target && pi / 2 >= 128 && ((pi / 2) & 3u) == 0 &&
+           maxnonce / (pi / 2) < (1ull << 31) && (maxnonce / (pi / 2)) % block == 0) pi /= 2;
+    return pi;
+}
+extern "C" int bsgs_debug_narrow_batching(uint64_t giants_per_tile, uint32_t default_giants_per_thread, uint32_t ntiles, uint32_t cus, uint32_t block,
+                                          uint32_t *giants_per_thread)
+{
+    if (!giants_per_thread) return fail(BSGS_ERR_ARG, "null");
+    *giants_per_thread = narrow_pi(giants_per_tile, default_giants_per_thread, ntiles, cus, block);
+    return BSGS_OK;
+}
 static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles, int which)
 {
     if (d->narrow_off || which || d->nstreams != 1 || d->digest || d->debug_flags || d->phase_probe || !lines_layout(d)) return nullptr;
     if ((d->variant != 10 && d->variant != 13) || (d->pi & 3u)) return nullptr;
     if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) return nullptr;        // the quirk list is indexed by the default batching
-    const uint64_t target = (uint64_t)d->prop.multiProcessorCount * 1024;                        // four blocks of 256 threads per CU
-    uint32_t pi = d->pi;
-    while ((uint64_t)ntiles * (d->maxnonce / pi) < target && pi / 2 >= 128 && ((pi / 2) & 3u) == 0 &&
-           d->maxnonce / (pi / 2) < (1ull << 31) && (d->maxnonce / (pi / 2)) % d->block_size == 0) pi /= 2;
+    const uint32_t pi = narrow_pi(d->maxnonce, d->pi, ntiles, (uint32_t)d->prop.multiProcessorCount, d->block_size);
     if (pi == d->pi) return nullptr;
     for (const auto &b : d->narrow) if (b.pi == pi) return &b;
     // build it: 64 bytes per giant once more.  Not at the expense of anything else: only while twice that much (and 2 GiB) is free

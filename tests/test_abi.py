@@ -57,3 +57,32 @@ def test_product_does_not_link_or_import_the_oracle(libpath):
             if f.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in src and "oracle_lib" not in src and "curve64_ref" not in src, f
+
+
+def test_narrow_batching_rule(libpath):
+    """bsgs_debug_narrow_batching = the rule a launch's batching follows (bsgs_hip.hip narrow_pi), no device needed: a launch of few tiles halves
+    the giants per thread until it has four blocks of 256 threads per CU, never below 128, never to an odd or non-multiple-of-4 batch, never to a
+    thread count that is not a multiple of the block; launches that fill the GPU (and geometries too small to split) keep the default."""
+    L = ctypes.CDLL(libpath)
+    L.bsgs_debug_narrow_batching.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.POINTER(ctypes.c_uint32)]
+
+    def rule(n, pi, ntiles, cus=256, block=256):
+        out = ctypes.c_uint32()
+        assert L.bsgs_debug_narrow_batching(n, pi, ntiles, cus, block, ctypes.byref(out)) == 0
+        return out.value
+
+    n = 1 << 24                                               # -t 256 -b 256 -p 256; default batching 16384 threads x 1024 giants
+    assert [rule(n, 1024, k) for k in (1, 2, 3, 4, 7, 8, 12, 15, 16, 48, 192)] == [128, 128, 128, 256, 256, 512, 512, 512, 1024, 1024, 1024]
+    assert rule(n, 1024, 1, cus=64) == 256                    # a smaller GPU is full sooner
+    assert rule(n, 1024, 0) == 128 and rule(n, 1024, 1 << 20) == 1024
+    # -t 128 -b 3 -p 256 (the fuzz geometry): 98304 giants, default 384 threads x 256 -> 768 x 128 ; 96 x 1024 cannot split (96 % 256)
+    assert rule(128 * 3 * 256, 256, 1) == 128
+    assert rule(96 * 1024, 1024, 1) == 1024
+    # batch lengths that are not powers of two: 264 = 8 * 33 -> 132 (still a multiple of 4, >= 128); 260 -> 130 is not a multiple of 4; 520 -> 260 -> stop
+    assert rule(256 * 264 * 8, 264, 1) == 132
+    assert rule(256 * 260 * 8, 260, 1) == 260
+    assert rule(256 * 520 * 8, 520, 1) == 260
+    # nothing to do for odd / tiny / inconsistent input
+    assert rule(1000, 10, 1) == 10 and rule(1 << 24, 1023, 1) == 1023 and rule(12345, 256, 1) == 256
+    assert L.bsgs_debug_narrow_batching(n, 1024, 1, 256, 256, None) != 0
