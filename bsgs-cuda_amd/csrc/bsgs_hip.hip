@@ -306,8 +306,12 @@ static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
     const uint64_t per_giant = halfchain ? ((d->variant == 13 && (d->pi & 3u) == 0) ? 8 : 16) : 32;             // as ensure_chain sizes the scratch
     if (d->nstreams == 1 && bsgs_mem_available(&fr, &tot) == hipSuccess) {
         fr += d->chain_bytes + d->group0_reserve.size() * d->group0_piece_bytes;     // what is already ours (scratch, reserve) counts as available
-        for (uint64_t mult = 4; mult > 1; mult /= 2)
-            if (n * mult <= BSGS_TILES_PER_LAUNCH_MAX && n * mult * d->maxnonce * per_giant <= fr / 3) { n *= mult; break; }
+        // ... and tiles smaller than the usual 2^24 giants (the reference's README runs -t 256 -b 88 -p 130: 2.9 M) get more of them, so that a launch is the
+        // same WORK -- 192 x 2^24 giants -- whatever the geometry: 192 tiles of 2.9 M giants are 30 ms launches and 37.3 G (profiles/r05h_*), the boundary
+        // costs what it costs.  Up to BSGS_TILES_PER_LAUNCH_MAX tiles, memory permitting as before.
+        const uint64_t work = std::min<uint64_t>(std::max<uint64_t>((192ull << 24) / std::max<uint64_t>(d->maxnonce, 1), n * 4), BSGS_TILES_PER_LAUNCH_MAX);
+        for (uint64_t cand = work; cand > n; cand = (cand + 1) / 2)
+            if (cand * d->maxnonce * per_giant <= fr / 3) { n = cand; break; }
     }
     const_cast<bsgs_dev *>(d)->auto_tpl = (uint32_t)n;           // decided once per geometry / table (reset by set_geometry, free_table)
     return (uint32_t)n;
