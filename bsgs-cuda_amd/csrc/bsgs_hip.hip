@@ -555,10 +555,10 @@ static int ensure_centres(bsgs_dev *d, uint64_t tiles)
 // with many tiles per launch.  A launch of ONE tile -- the reference's own launch pattern (1_9_7File.pb:2442-2459), what route A does whenever the
 // centres cannot be predicted, what bsgs_step is -- then occupies 64 blocks of a 256-CU GPU: 6.5 G giant steps/s.  Any factorisation Ti' x pi' of
 // maxnonce numbers the giants the same way (i = thread * pi' + slot), so such a launch takes a second copy of the giants laid out for shorter
-// batches and more threads: the longest batch (>= 128 giants: below that the Fermat inversion, 270 multiplications per thread, costs more than the
-// occupancy brings) that still gives the launch four blocks per CU.  profiles/r04n_one_tile_launch_batching.log: 1 tile 6.5 -> 25.8 G, 4 tiles 25.3 -> 33.2 G.
+// batches and more threads: the longest batch (>= 128 giants: below that the Fermat inversion -- 279 multiplications on the critical path of every block --
+// costs more than the occupancy brings: 262144 x 64 runs one tile at 24.6 G, 131072 x 128 at 26.2 G) that still gives the launch four blocks per CU.  profiles/r04n_one_tile_launch_batching.log: 1 tile 6.5 -> 25.8 G, 4 tiles 25.3 -> 33.2 G.
 static bool lines_layout(const bsgs_dev *d);
-// the rule itself (no device needed: tests/test_host_logic.py drives it through bsgs_debug_narrow_batching)
+// the rule itself (no device needed: tests/test_abi.py drives it through bsgs_debug_narrow_batching)
 static uint32_t narrow_pi(uint64_t maxnonce, uint32_t pi, uint32_t ntiles, uint32_t cus, uint32_t block)
 {
     const uint64_t target = (uint64_t)cus * 1024;                                                // four blocks of 256 threads per CU
