@@ -29,7 +29,72 @@ int bsgs_fail(int code, const char *fmt, ...)
 }
 
 extern "C" const char *bsgs_last_error(void) { return g_err.c_str(); }
-extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.1 (gfx950)"; }
+extern "C" const char *bsgs_version(void) { return "bsgs-hip 0.4 (gfx950)"; }
+// The -D switches this library was built with, space separated; "" for the shipped build.  "WRONG-RESULTS:" prefixes the *_CEILING
+// switches (timing experiments whose hit lists are wrong by construction: they compile only with -DBSGS_EXPERIMENT).
+extern "C" const char *bsgs_build_info(void)
+{
+    static const std::string info = [] {
+        std::string s;
+        auto add = [&](const char *n) { if (!s.empty()) s += ' '; s += n; };
+#define SW(name) add(#name)
+#define WRONG(name) add("WRONG-RESULTS:" #name)
+#ifdef BSGS_EXPERIMENT
+        SW(BSGS_EXPERIMENT);
+#endif
+#ifdef BSGS_NO_OVF_CEILING
+        WRONG(BSGS_NO_OVF_CEILING);
+#endif
+#ifdef BSGS_QUAD_CEILING
+        WRONG(BSGS_QUAD_CEILING);
+#endif
+#ifdef BSGS_NOCHAIN_CEILING
+        WRONG(BSGS_NOCHAIN_CEILING);
+#endif
+#ifdef BSGS_NOCHAIN_STORE_CEILING
+        WRONG(BSGS_NOCHAIN_STORE_CEILING);
+#endif
+#ifdef BSGS_NOCHAIN_LOAD_CEILING
+        WRONG(BSGS_NOCHAIN_LOAD_CEILING);
+#endif
+#ifdef BSGS_OCT_CEILING
+        WRONG(BSGS_OCT_CEILING);
+#endif
+#ifdef BSGS_G2_DUP_CEILING
+        WRONG(BSGS_G2_DUP_CEILING);
+#endif
+#ifdef BSGS_G2_CACHED_CEILING
+        WRONG(BSGS_G2_CACHED_CEILING);
+#endif
+#ifdef BSGS_FULL_X
+        SW(BSGS_FULL_X);
+#endif
+#ifdef BSGS_INV_PER_WAVE
+        SW(BSGS_INV_PER_WAVE);
+#endif
+#ifdef FE_FOLD_EXACT_ONLY
+        SW(FE_FOLD_EXACT_ONLY);
+#endif
+#ifdef FE_FOLD_C
+        SW(FE_FOLD_C);
+#endif
+#ifdef FE_FOLD_COLUMNS
+        SW(FE_FOLD_COLUMNS);
+#endif
+#ifdef FE_SQR_VIA_MUL
+        SW(FE_SQR_VIA_MUL);
+#endif
+        if (BSGS_PAIR2_WAVES != 4) add("BSGS_PAIR2_WAVES=" BSGS_STR(BSGS_PAIR2_WAVES));
+        if (BSGS_TILE_CHUNK != 64u) add("BSGS_TILE_CHUNK=" BSGS_STR(BSGS_TILE_CHUNK));
+        if (BSGS_NT_CHAIN != 1) add("BSGS_NT_CHAIN=" BSGS_STR(BSGS_NT_CHAIN));
+        if (BSGS_NT_LINES != 0) add("BSGS_NT_LINES=" BSGS_STR(BSGS_NT_LINES));
+        if (BSGS_PROBE_CPOL != 2) add("BSGS_PROBE_CPOL=" BSGS_STR(BSGS_PROBE_CPOL));
+#undef SW
+#undef WRONG
+        return s;
+    }();
+    return info.c_str();
+}
 
 static void release_pending(bsgs_dev *d);
 
@@ -51,18 +116,17 @@ extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
     HIPCHK(hipSetDevice(device_id));
     bsgs_dev *d = new bsgs_dev();
     d->id = device_id;
-    if (const char *v = getenv("BSGS_KERNEL_VARIANT")) d->variant = atoi(v);      // tuning/A-B only; all variants are bit-identical
+    if (const char *v = getenv("BSGS_KERNEL_VARIANT")) {                          // A-B and tests only; the variants are bit-identical
+        const int k = atoi(v);
+        if (k != 13 && k != 10 && k != 0) { delete d; return fail(BSGS_ERR_ARG, "BSGS_KERNEL_VARIANT=%d: this library has 13 (default), 10 and 0", k); }
+        d->variant = k;
+    }
     HIPCHK(hipGetDeviceProperties(&d->prop, device_id));
     HIPCHK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&d->ev0));
     HIPCHK(hipEventCreate(&d->ev1));
-    HIPCHK(hipEventCreate(&d->ev2));
-    HIPCHK(hipEventCreateWithFlags(&d->evj, hipEventDisableTiming));
     if (const char *v = getenv("BSGS_DEBUG_PHASES")) d->debug_flags = (unsigned)atoi(v);     // timing experiments only
-    if (const char *v = getenv("BSGS_BLOCK")) { int bsz = atoi(v); if (bsz == 64 || bsz == 128 || bsz == 256) d->block_size = (unsigned)bsz; }
-    if (const char *v = getenv("BSGS_STREAMS")) d->nstreams = atoi(v) == 2 ? 2 : 1;     // tuning / A-B only
-    if (const char *v = getenv("BSGS_NARROW_LAUNCHES")) d->narrow_off = atoi(v) == 0;     // A-B only: 0 = every launch with the default batching
+    if (const char *v = getenv("BSGS_NARROW_LAUNCHES")) d->narrow_env_off = atoi(v) == 0; // A-B only: 0 = every launch with the default batching
     HIPCHK(hipMalloc(&d->hitbuf, hitbuf_bytes(d)));
     HIPCHK(hipHostMalloc(&d->hit_host, hitbuf_bytes(d), hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(d->hitbuf, 0, 64, d->stream));
@@ -77,6 +141,7 @@ static void free_table(bsgs_dev *d)
     if (d->lines && d->lines_owned) (void)hipFree(d->lines);
     if (d->ovf && d->lines_owned) (void)hipFree(d->ovf);
     d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true; d->auto_tpl = 0;
+    d->narrow_off = false;                  // memory was short for a narrow copy of the giants ONCE: another table, another try
 }
 void bsgs_free_table(bsgs_dev *d) { free_table(d); }
 void bsgs_free_recv(bsgs_dev *d)
@@ -96,12 +161,9 @@ static void free_g2(bsgs_dev *d)
     free_narrow(d);
     if (d->chain) (void)hipFree(d->chain);
     free_chain_pieces(d);
-    if (d->schain) (void)hipFree(d->schain);
-    if (d->pool) (void)hipFree(d->pool);
-    d->pool = nullptr;
     if (d->quirk_list) (void)hipFree(d->quirk_list);
     d->quirk_list = nullptr; d->quirk_host.clear(); d->quirk_ready = false;
-    d->g2 = nullptr; d->chain = nullptr; d->chain_bytes = 0; d->schain = nullptr; d->schain_blocks = 0;
+    d->g2 = nullptr; d->chain = nullptr; d->chain_bytes = 0;
 }
 
 extern "C" int bsgs_dev_close(bsgs_dev *d)
@@ -120,9 +182,8 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     if (d->cen_pin) (void)hipHostFree(d->cen_pin);
     if (d->walk_table) (void)hipFree(d->walk_table);
     if (d->digest) (void)hipFree(d->digest);
-    (void)hipStreamSynchronize(d->stream2);
-    (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1); (void)hipEventDestroy(d->ev2); (void)hipEventDestroy(d->evj);
-    (void)hipStreamDestroy(d->stream); (void)hipStreamDestroy(d->stream2);
+    (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1);
+    (void)hipStreamDestroy(d->stream);
     delete d;
     return BSGS_OK;
 }
@@ -221,7 +282,7 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     if (T >= (1ull << 31) || maxnonce >= (1ull << 32)) return fail(BSGS_ERR_ARG, "t*b*p must be < 2^32 (hit index is u32)");
     HIPCHK(hipSetDevice(d->id));
     free_g2(d);
-    d->t = t; d->b = b; d->p = p; d->T = T; d->maxnonce = maxnonce; d->auto_tpl = 0;
+    d->t = t; d->b = b; d->p = p; d->T = T; d->maxnonce = maxnonce; d->auto_tpl = 0; d->narrow_off = false;
     // Internal batching: one Fermat inversion (270 multiplications) is shared by pi giants of a thread, so a
     // longer batch is cheaper per giant step; the thread count lost that way is won back by putting more tiles
     // in one launch.  Grow pi up to ~2048 while Ti stays a multiple of 256 threads and >= 2048.
@@ -234,33 +295,46 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
     return BSGS_OK;
 }
 
-// the prefix-product scratch: 32 bytes per giant per tile in flight (16 for the pair-batched default kernel, which stores
-// one product per two giants); `full` = the caller is a generator kernel that needs the per-giant chain of one tile
+static bool lines_layout(const bsgs_dev *d) { return d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128; }
+// giants per stored running product of the tile kernel a launch with batch length `pi` takes: 4 / 2 = the chained kernel (giant_pair2_kernel,
+// QUAD or not), 1 = the per-giant kernel (CSR layout, odd batch lengths, BSGS_KERNEL_VARIANT=0)
+static uint32_t chain_group(const bsgs_dev *d, uint32_t pi)
+{
+    if (d->variant == 0 || !lines_layout(d) || (pi & 1u)) return 1;
+    return (d->variant == 13 && (pi & 3u) == 0) ? 4 : 2;
+}
+
+// the prefix-product scratch per tile in flight: 32 bytes per giant for the per-giant kernel, 16 / 8 for the chained kernel (one stored
+// product per two / four giants); `full` = the caller is a generator kernel that needs the per-giant chain of one tile
 static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
 {
-    const bool halfchain = !full && (d->variant == 10 || d->variant == 11 || d->variant == 13) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);   // = the dispatch of giant_pair2_kernel
+    const uint32_t group = full ? 1 : chain_group(d, d->pi);
+    const bool chained = group > 1;
     // the tiles' scratch areas are 2^28 bytes apart at the usual geometry; tiles of a launch touch the same offsets at about the
-    // same time, so a pad breaks the power-of-two stride between them (BSGS_CHAIN_PAD bytes, pair-batched kernel only)
+    // same time, so a pad breaks the power-of-two stride between them (BSGS_CHAIN_PAD bytes, chained kernel only: an experiment that changed nothing)
     static const uint64_t pad_env = getenv("BSGS_CHAIN_PAD") ? strtoull(getenv("BSGS_CHAIN_PAD"), nullptr, 10) : 0;
-    d->chain_pad = halfchain ? (uint32_t)(pad_env / 16) : 0;
-    // the pair-batched kernel's scratch is [tile][block][pair][2][block size]: whole blocks (the tail block is padded)
+    d->chain_pad = chained ? (uint32_t)(pad_env / 16) : 0;
+    // the chained kernel's scratch is [tile][block][group][2][block size]: whole blocks (the tail block is padded)
     const uint64_t threads_padded = ((uint64_t)d->Ti + d->block_size - 1) / d->block_size * d->block_size;
-    const bool quad = halfchain && d->variant == 13 && (d->pi & 3u) == 0;                                          // one stored product per four giants: 8 bytes per giant
-    const uint64_t per_tile = (halfchain ? threads_padded * d->pi * (quad ? 8 : 16) : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16;
-    const uint64_t per_stream = per_tile * tiles;
-    const uint64_t bytes = per_stream * (d->nstreams == 2 ? 2 : 1);                 // one scratch per stream
+    const uint64_t per_tile = (chained ? threads_padded * d->pi * (32 / group) : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16;
+    const uint64_t bytes = per_tile * tiles;
     static const bool pieces_on = !(getenv("BSGS_CHAIN_PIECES") && atoi(getenv("BSGS_CHAIN_PIECES")) == 0);
-    if (pieces_on && halfchain && d->nstreams == 1 && bytes >= (8ull << 30) && per_tile <= (4ull << 30)) {
+    if (pieces_on && chained && bytes >= (8ull << 30) && per_tile <= (4ull << 30)) {
         uint32_t lg = 0;
         while ((per_tile << (lg + 1)) <= (4ull << 30)) lg++;                       // pieces of 2^lg tiles, at most 4 GiB
         const uint64_t piece_bytes = per_tile << lg, npieces = (tiles + (1ull << lg) - 1) >> lg;
         if (npieces <= BSGS_CHAIN_PIECES_MAX) {
             if (!d->chain_pieces.empty() && d->chain_piece_bytes == piece_bytes && d->chain_piece_log == lg && d->chain_pieces.size() >= npieces) return BSGS_OK;
-            HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2));
+            HIPCHK(hipStreamSynchronize(d->stream));
             free_chain_pieces(d);
             if (d->chain) { (void)hipFree(d->chain); d->chain = nullptr; }
             d->chain_bytes = 0;
-            if (!alloc_graded_pieces(d, npieces, piece_bytes)) {
+            bool got = alloc_graded_pieces(d, npieces, piece_bytes);
+            if (!got && !d->narrow.empty()) {                                       // the narrow copies of the giants are a convenience: they go first
+                free_narrow(d);
+                got = alloc_graded_pieces(d, npieces, piece_bytes);
+            }
+            if (!got) {
                 size_t fr = 0, tot = 0;
                 (void)bsgs_mem_available(&fr, &tot);
                 return fail(BSGS_ERR_NOMEM, "chain scratch: %llu pieces of %.1f GiB for %llu tiles in flight, %.1f of %.1f GiB free", (unsigned long long)npieces,
@@ -268,18 +342,19 @@ static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
             }
             d->chain_piece_bytes = piece_bytes; d->chain_piece_log = lg;
             d->chain_bytes = piece_bytes * npieces;
-            d->chain_stride = per_stream / 16;
             return BSGS_OK;
         }
     }
-    if (!d->chain_pieces.empty()) {                                                 // back to one buffer (a generator kernel, another variant)
-        HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2));
+    if (!d->chain_pieces.empty()) {                                                 // back to one buffer (a generator kernel, the per-giant kernel)
+        HIPCHK(hipStreamSynchronize(d->stream));
         free_chain_pieces(d);
         d->chain_bytes = 0;
     }
-    if (d->chain && d->chain_bytes >= bytes) { d->chain_stride = per_stream / 16; return BSGS_OK; }
-    if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
-    if (bsgs_big_malloc(&d->chain, bytes) != hipSuccess) {
+    if (d->chain && d->chain_bytes >= bytes) return BSGS_OK;
+    if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
+    hipError_t e = bsgs_big_malloc(&d->chain, bytes);
+    if (e != hipSuccess && !d->narrow.empty()) { (void)hipGetLastError(); (void)hipStreamSynchronize(d->stream); free_narrow(d); e = bsgs_big_malloc(&d->chain, bytes); }
+    if (e != hipSuccess) {
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
         d->chain = nullptr;
@@ -287,7 +362,6 @@ static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
                     (unsigned long long)tiles, fr / 1073741824.0, tot / 1073741824.0);
     }
     d->chain_bytes = bytes;
-    d->chain_stride = per_stream / 16;
     return BSGS_OK;
 }
 static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
@@ -299,17 +373,17 @@ static uint32_t auto_tiles_per_launch(const bsgs_dev *d)
     // tiles (44.7 ms); the centres live in device memory, so nothing but the chain scratch (8 bytes x giants per tile in flight; 16 with the pair chain)
     // limits a launch: measured 36.0 / 37.3 / 37.5 G giant-steps/s at 48 / 96 / 192 tiles (profiles/r02a_ab_tiles_per_launch.log).
     // Take 4x the fill-the-chip figure when that scratch fits in a third of the free memory, else 2x, else 1x.
-    const uint64_t want = (uint64_t)d->prop.multiProcessorCount * (d->nstreams == 2 ? 512 : 3072);
+    const uint64_t want = (uint64_t)d->prop.multiProcessorCount * 3072;
     uint64_t n = std::min<uint64_t>(std::max<uint64_t>((want + d->Ti - 1) / d->Ti, 1), BSGS_TILES_PER_LAUNCH);
     size_t fr = 0, tot = 0;
-    const bool halfchain = (d->variant == 10 || d->variant == 11 || d->variant == 13) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128);
-    const uint64_t per_giant = halfchain ? ((d->variant == 13 && (d->pi & 3u) == 0) ? 8 : 16) : 32;             // as ensure_chain sizes the scratch
-    if (d->nstreams == 1 && bsgs_mem_available(&fr, &tot) == hipSuccess) {
+    const uint64_t per_giant = 32 / chain_group(d, d->pi);                          // as ensure_chain sizes the scratch
+    if (bsgs_mem_available(&fr, &tot) == hipSuccess) {
         fr += d->chain_bytes + d->group0_reserve.size() * d->group0_piece_bytes;     // what is already ours (scratch, reserve) counts as available
         // ... and tiles smaller than the usual 2^24 giants (the reference's README runs -t 256 -b 88 -p 130: 2.9 M) get more of them, so that a launch is the
         // same WORK -- 192 x 2^24 giants -- whatever the geometry: 192 tiles of 2.9 M giants are 30 ms launches and 37.3 G (profiles/r05h_*), the boundary
         // costs what it costs.  Up to BSGS_TILES_PER_LAUNCH_MAX tiles, memory permitting as before.
         const uint64_t work = std::min<uint64_t>(std::max<uint64_t>((192ull << 24) / std::max<uint64_t>(d->maxnonce, 1), n * 4), BSGS_TILES_PER_LAUNCH_MAX);
+        // (a launch of few tiles may add ONE narrow copy of the giants, 64 bytes per giant: pick_batching; it is built only while twice that is free)
         for (uint64_t cand = work; cand > n; cand = (cand + 1) / 2)
             if (cand * d->maxnonce * per_giant <= fr / 3) { n = cand; break; }
     }
@@ -557,7 +631,6 @@ static int ensure_centres(bsgs_dev *d, uint64_t tiles)
 // maxnonce numbers the giants the same way (i = thread * pi' + slot), so such a launch takes a second copy of the giants laid out for shorter
 // batches and more threads: the longest batch (>= 128 giants: below that the Fermat inversion -- 279 multiplications on the critical path of every block --
 // costs more than the occupancy brings: 262144 x 64 runs one tile at 24.6 G, 131072 x 128 at 26.2 G) that still gives the launch four blocks per CU.  profiles/r04n_one_tile_launch_batching.log: 1 tile 6.5 -> 25.8 G, 4 tiles 25.3 -> 33.2 G.
-static bool lines_layout(const bsgs_dev *d);
 // the rule itself (no device needed: tests/test_abi.py drives it through bsgs_debug_narrow_batching)
 static uint32_t narrow_pi(uint64_t maxnonce, uint32_t pi, uint32_t ntiles, uint32_t cus, uint32_t block)
 {
@@ -574,21 +647,30 @@ extern "C" int bsgs_debug_narrow_batching(uint64_t giants_per_tile, uint32_t def
     *giants_per_thread = narrow_pi(giants_per_tile, default_giants_per_thread, ntiles, cus, block);
     return BSGS_OK;
 }
-static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles, int which)
+// At most ONE narrow copy is resident (64 bytes per giant): a launch size that wants another batching replaces it (the compat layer's 4 / 8 / 16-tile
+// ramp and a ragged last launch would otherwise collect three), and bsgs_prepare builds the one-tile copy at start-up so that a job's clock never
+// contains the allocation and the re-batching pass.
+static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles)
 {
-    if (d->narrow_off || which || d->nstreams != 1 || d->digest || d->debug_flags || d->phase_probe || !lines_layout(d)) return nullptr;
-    if ((d->variant != 10 && d->variant != 13) || (d->pi & 3u)) return nullptr;
+    if (d->narrow_off || d->narrow_env_off || d->digest || d->debug_flags || d->phase_probe) return nullptr;
+    if (chain_group(d, d->pi) != 4) return nullptr;
     if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) return nullptr;        // the quirk list is indexed by the default batching
     const uint32_t pi = narrow_pi(d->maxnonce, d->pi, ntiles, (uint32_t)d->prop.multiProcessorCount, d->block_size);
     if (pi == d->pi) return nullptr;
     for (const auto &b : d->narrow) if (b.pi == pi) return &b;
     // build it: 64 bytes per giant once more.  Not at the expense of anything else: only while twice that much (and 2 GiB) is free
-    size_t fr = 0, tot = 0;
     const uint64_t bytes = d->maxnonce * 64;
-    if (bsgs_mem_available(&fr, &tot) != hipSuccess || fr < 2 * bytes + (2ull << 30)) { d->narrow_off = true; return nullptr; }
     bsgs_dev::Batching nb;
     nb.pi = pi; nb.Ti = (uint32_t)(d->maxnonce / pi);
-    if (bsgs_big_malloc(&nb.g2, bytes) != hipSuccess) { (void)hipGetLastError(); d->narrow_off = true; return nullptr; }     // like d->g2
+    if (!d->narrow.empty()) {                                    // re-use the resident copy's memory: launches in flight may still read it
+        if (hipStreamSynchronize(d->stream) != hipSuccess) return nullptr;
+        nb.g2 = d->narrow[0].g2;
+        d->narrow.clear();
+    } else {
+        size_t fr = 0, tot = 0;
+        if (bsgs_mem_available(&fr, &tot) != hipSuccess || fr < 2 * bytes + (2ull << 30)) { d->narrow_off = true; return nullptr; }
+        if (bsgs_big_malloc(&nb.g2, bytes) != hipSuccess) { (void)hipGetLastError(); d->narrow_off = true; return nullptr; }     // like d->g2
+    }
     const int blocks = (int)std::min<uint64_t>((d->maxnonce + 255) / 256, 65535);
     hipLaunchKernelGGL(g2_rebatch_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)d->g2, d->Ti, d->pi, nb.g2, nb.Ti, nb.pi, d->maxnonce);
     if (hipGetLastError() != hipSuccess) { (void)hipFree(nb.g2); d->narrow_off = true; return nullptr; }
@@ -597,23 +679,22 @@ static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles, int
 }
 
 static int quirk_prepare(bsgs_dev *d);
-static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uint32_t seq, int which)
+static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uint32_t seq)
 {
     TileArgs A;
-    hipStream_t st = which ? d->stream2 : d->stream;
-    const bsgs_dev::Batching *nb = pick_batching(d, ntiles, which);
+    hipStream_t st = d->stream;
+    const bsgs_dev::Batching *nb = pick_batching(d, ntiles);
     const uint32_t Ti = nb ? nb->Ti : d->Ti, pi = nb ? nb->pi : d->pi;
     d->last_Ti = Ti; d->last_pi = pi;
-    d->last_kernel = "another variant (BSGS_KERNEL_VARIANT / CSR layout / odd chain length)";
-    A.g2 = nb ? nb->g2 : d->g2; A.chain = d->chain + (which ? d->chain_stride : 0); A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
+    A.g2 = nb ? nb->g2 : d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = pi; A.T = Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;
-    A.centres_dev = centres_dev; A.pool = nullptr; A.pool_cap = 0; A.pool_stride = 0;
+    A.centres_dev = centres_dev;
     A.digest = d->digest ? d->digest + (uint64_t)seq * Ti * 2 : nullptr;
     A.chain_pad = d->chain_pad; A.chain_mode = 0;
     for (int k = 0; k < BSGS_CHAIN_PIECES_MAX; k++) A.chain_piece[k] = nullptr;
-    if (!d->chain_pieces.empty()) {                        // pair-batched kernel, one stream (ensure_chain)
+    if (!d->chain_pieces.empty()) {                        // chained kernel (ensure_chain)
         A.chain = nullptr; A.chain_mode = d->chain_piece_log + 1;
         for (size_t k = 0; k < d->chain_pieces.size(); k++) A.chain_piece[k] = d->chain_pieces[k];
     }
@@ -626,53 +707,14 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
         HIPCHK(hipGetLastError());
     }
     const dim3 grid((unsigned)(((Ti + bs - 1) / bs) * ntiles)), block(bs);
-    if (d->variant == 6 && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
-        if (d->layout == BSGS_TABLE_LINES64) hipLaunchKernelGGL(giant_pair_kernel<2>, grid, block, 0, st, A);
-        else                                 hipLaunchKernelGGL(giant_pair_kernel<3>, grid, block, 0, st, A);
-        HIPCHK(hipGetLastError());
-        return BSGS_OK;
-    }
-    if (d->variant == 13 && (pi & 3u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
-        // QUAD: one stored product per four giants, one probe in flight per wave (giant_kernel.hip.h); same LDS footprint as the pair kernel
-        const bool l128 = d->layout == BSGS_TABLE_LINES128;
-        const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048);
-        const bool dbg = d->debug_flags != 0 || d->phase_probe;
-        if (l128) { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<3, true, false, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<3, false, false, true>), grid, block, lds, st, A); }
-        else      { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<2, true, false, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<2, false, false, true>), grid, block, lds, st, A); }
-        HIPCHK(hipGetLastError());
-        d->last_kernel = l128 ? (dbg ? "giant_pair2_kernel<3, true, false, true>" : "giant_pair2_kernel<3, false, false, true>")
-                              : (dbg ? "giant_pair2_kernel<2, true, false, true>" : "giant_pair2_kernel<2, false, false, true>");
-        return BSGS_OK;
-    }
-    if ((d->variant == 10 || d->variant == 11 || d->variant == 13) && (d->pi & 1u) == 0 && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
-        const bool l128 = d->layout == BSGS_TABLE_LINES128;
-        const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048);           // probe slots + S stash per wave: 4 blocks fill the 160 KiB of a CU exactly
-        const bool dbg = d->debug_flags != 0 || d->phase_probe;
-        if (l128) { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<3, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<3, false>), grid, block, lds, st, A); }
-        else      { if (dbg) hipLaunchKernelGGL((giant_pair2_kernel<2, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_pair2_kernel<2, false>), grid, block, lds, st, A); }
-        HIPCHK(hipGetLastError());
-        d->last_kernel = l128 ? (dbg ? "giant_pair2_kernel<3, true, false, false>" : "giant_pair2_kernel<3, false, false, false>")
-                              : (dbg ? "giant_pair2_kernel<2, true, false, false>" : "giant_pair2_kernel<2, false, false, false>");
-        return BSGS_OK;
-    }
-    if (((d->variant >= 9 && d->variant <= 11) || d->variant == 13) && (d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128)) {
-        const bool l128 = d->layout == BSGS_TABLE_LINES128;
-        const size_t lds = (size_t)(bs / 64) * 2 * (l128 ? 8192 : 4096);
-        const bool dbg = d->debug_flags != 0 || d->phase_probe;
-        if (l128) { if (dbg) hipLaunchKernelGGL((giant_tile2_kernel<3, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_tile2_kernel<3, false>), grid, block, lds, st, A); }
-        else      { if (dbg) hipLaunchKernelGGL((giant_tile2_kernel<2, true>), grid, block, lds, st, A); else hipLaunchKernelGGL((giant_tile2_kernel<2, false>), grid, block, lds, st, A); }
-        HIPCHK(hipGetLastError());
-        return BSGS_OK;
-    }
-    const int var = (d->variant == 7 || d->variant == 8) ? d->variant : d->variant >= 3 ? 1 : d->variant;
-    const size_t lds8 = var == 8 ? (size_t)(bs / 64) * (d->layout == BSGS_TABLE_LINES128 ? 8192 : 4096) : 0;
-#define LAUNCH(M, V) hipLaunchKernelGGL((giant_tile_kernel<M, V>), grid, block, (V == 8 ? lds8 : 0), st, A)
-    switch (d->layout) {
-    case BSGS_TABLE_LINES64:  if (var == 0) LAUNCH(2, 0); else if (var == 1) LAUNCH(2, 1); else if (var == 7) LAUNCH(2, 7); else if (var == 8) LAUNCH(2, 8); else LAUNCH(2, 2); break;
-    case BSGS_TABLE_LINES128: if (var == 0) LAUNCH(3, 0); else if (var == 1) LAUNCH(3, 1); else if (var == 7) LAUNCH(3, 7); else if (var == 8) LAUNCH(3, 8); else LAUNCH(3, 2); break;
-    default:                  LAUNCH(0, 0); break;
-    }
-#undef LAUNCH
+    const uint32_t group = chain_group(d, pi);
+    // chained kernel, per wave: two probe slots (QUAD: one probe slot + the two 2 KiB temporaries) + the 2 KiB S stash: 4 blocks fill the 160 KiB of a CU exactly
+    const bool l128 = d->layout == BSGS_TABLE_LINES128;
+    const size_t lds = group > 1 ? (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048) : 0;
+    const bool dbg = d->debug_flags != 0 || d->phase_probe;
+    if (d->layout == BSGS_TABLE_LINES64) HIPCHK(bsgs_launch_tile_lines64(A, grid, block, lds, st, group, dbg, &d->last_kernel));
+    else if (l128)                       HIPCHK(bsgs_launch_tile_lines128(A, grid, block, lds, st, group, dbg, &d->last_kernel));
+    else { hipLaunchKernelGGL((giant_tile_kernel<0>), grid, block, 0, st, A); d->last_kernel = "giant_tile_kernel<0>"; }
     HIPCHK(hipGetLastError());
     return BSGS_OK;
 }
@@ -682,111 +724,6 @@ static void release_pending(bsgs_dev *d)
     for (void *p : d->pending_dev) (void)hipFree(p);
     for (void *p : d->pending_pinned) (void)hipHostFree(p);
     d->pending_dev.clear(); d->pending_pinned.clear();
-}
-
-// one launch for the whole batch: every resident block walks a sequence of tiles (giant_stream_kernel)
-static int launch_stream(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq)
-{
-    const unsigned bs = d->block_size;
-    const uint32_t nb = (uint32_t)((d->Ti + bs - 1) / bs);
-    int per_cu = 0;
-    const bool l128 = d->layout == BSGS_TABLE_LINES128;
-    const bool ldsp = d->variant == 4, full = d->variant == 5;
-    const size_t lds_bytes = full ? (size_t)(bs / 64) * (6144 + (l128 ? 8192 : 4096)) : ldsp ? (size_t)(bs / 64) * (l128 ? 8192 : 4096) : 0;
-    const void *fn = full ? (l128 ? (const void *)giant_stream_lds_kernel<3> : (const void *)giant_stream_lds_kernel<2>)
-                   : l128 ? (ldsp ? (const void *)giant_stream_kernel<3, true> : (const void *)giant_stream_kernel<3, false>)
-                          : (ldsp ? (const void *)giant_stream_kernel<2, true> : (const void *)giant_stream_kernel<2, false>);
-    if (lds_bytes > 65536) HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)bs, lds_bytes));
-    if (per_cu < 1) per_cu = 1;
-    const uint64_t resident = (uint64_t)per_cu * d->prop.multiProcessorCount;
-    uint32_t ng = (uint32_t)std::max<uint64_t>(1, resident / nb);
-    if (d->tiles_per_launch) ng = d->tiles_per_launch;            // explicit override (A-B experiments)
-    ng = std::min(ng, ntiles);
-    const uint64_t blocks = (uint64_t)nb * ng;
-    if (d->schain_blocks < blocks) {
-        HIPCHK(hipStreamSynchronize(d->stream));
-        if (d->schain) (void)hipFree(d->schain);
-        d->schain = nullptr; d->schain_blocks = 0;
-        HIPCHK(hipMalloc(&d->schain, blocks * d->pi * 2 * bs * 16));
-        d->schain_blocks = blocks;
-    }
-    void *pin = nullptr, *dc = nullptr;
-    HIPCHK(hipHostMalloc(&pin, (size_t)ntiles * 64, hipHostMallocDefault));
-    d->pending_pinned.push_back(pin);
-    memcpy(pin, centres, (size_t)ntiles * 64);
-    HIPCHK(hipMalloc(&dc, (size_t)ntiles * 64));
-    d->pending_dev.push_back(dc);
-    HIPCHK(hipMemcpyAsync(dc, pin, (size_t)ntiles * 64, hipMemcpyHostToDevice, d->stream));
-    StreamArgs S;
-    S.g2 = d->g2; S.chain = d->schain; S.csr = d->csr; S.lines = d->lines; S.ovf = d->ovf; S.ovf_n = d->ovf_n; S.hitbuf = d->hitbuf; S.centres = (const fe *)dc;
-    S.ht_items = d->ht_items; S.ht_mask = (u32)(d->ht_items - 1); S.pparam = d->pi; S.T = d->Ti; S.max_hits = d->max_hits;
-    S.tile_seq = seq; S.ntiles = ntiles; S.ngroups = ng; S.debug_flags = d->debug_flags;
-    const dim3 grid((unsigned)blocks), block(bs);
-    if (full) { if (l128) hipLaunchKernelGGL((giant_stream_lds_kernel<3>), grid, block, lds_bytes, d->stream, S);
-                else      hipLaunchKernelGGL((giant_stream_lds_kernel<2>), grid, block, lds_bytes, d->stream, S); }
-    else if (l128) { if (ldsp) hipLaunchKernelGGL((giant_stream_kernel<3, true>), grid, block, lds_bytes, d->stream, S);
-                else      hipLaunchKernelGGL((giant_stream_kernel<3, false>), grid, block, 0, d->stream, S); }
-    else      { if (ldsp) hipLaunchKernelGGL((giant_stream_kernel<2, true>), grid, block, lds_bytes, d->stream, S);
-                else      hipLaunchKernelGGL((giant_stream_kernel<2, false>), grid, block, 0, d->stream, S); }
-    HIPCHK(hipGetLastError());
-    return BSGS_OK;
-}
-
-// ---- pooled launch (BSGS_KERNEL_VARIANT=11): ONE launch for the whole queue.  The chain scratch belongs to resident blocks
-// (slots handed out by a per-XCD ring inside the kernel), the centres are read from device memory.
-static int ensure_pool(bsgs_dev *d)
-{
-    const uint32_t cap = 256;                                  // >= 2 x the 128 blocks of 256 threads one XCD holds at 4 waves per SIMD
-    if (!d->nxcc) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, d->id) != hipSuccess || n < 1) n = 8;
-        d->nxcc = (uint32_t)std::min(n, 16);
-    }
-    const uint64_t bytes = (uint64_t)d->nxcc * cap * d->pi * d->block_size * 16;       // [xcc][slot][pair][2][block] of 16 bytes, pi/2 pairs
-    if (!d->pool) {
-        const uint32_t stride = 16 + cap;
-        std::vector<uint32_t> h((size_t)d->nxcc * stride, 0);
-        for (uint32_t x = 0; x < d->nxcc; x++) for (uint32_t s = 0; s < cap; s++) h[(size_t)x * stride + 16 + s] = s;
-        HIPCHK(hipMalloc(&d->pool, h.size() * 4));
-        HIPCHK(hipMemcpy(d->pool, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-        d->pool_cap = cap; d->pool_stride = stride;
-    }
-    if (!d->chain_pieces.empty()) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); free_chain_pieces(d); d->chain_bytes = 0; }
-    if (d->chain && d->chain_bytes >= bytes) return BSGS_OK;
-    if (d->chain) { HIPCHK(hipStreamSynchronize(d->stream)); HIPCHK(hipStreamSynchronize(d->stream2)); (void)hipFree(d->chain); d->chain = nullptr; d->chain_bytes = 0; }
-    if (bsgs_big_malloc(&d->chain, bytes) != hipSuccess) { d->chain = nullptr; return fail(BSGS_ERR_NOMEM, "pooled chain scratch: %.1f GiB", bytes / 1073741824.0); }
-    d->chain_bytes = bytes;
-    return BSGS_OK;
-}
-
-static int launch_pooled(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, uint32_t seq)
-{
-    int rc = ensure_pool(d);
-    if (rc) return rc;
-    void *pin = nullptr, *dc = nullptr;
-    HIPCHK(hipHostMalloc(&pin, (size_t)ntiles * 64, hipHostMallocDefault));
-    d->pending_pinned.push_back(pin);
-    memcpy(pin, centres, (size_t)ntiles * 64);
-    HIPCHK(hipMalloc(&dc, (size_t)ntiles * 64));
-    d->pending_dev.push_back(dc);
-    HIPCHK(hipMemcpyAsync(dc, pin, (size_t)ntiles * 64, hipMemcpyHostToDevice, d->stream));
-    TileArgs A;
-    memset(&A, 0, sizeof A);
-    A.g2 = d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
-    A.chain_mode = 0;
-    for (int k = 0; k < BSGS_CHAIN_PIECES_MAX; k++) A.chain_piece[k] = nullptr;
-    A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = d->pi; A.T = d->Ti;
-    A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
-    A.centres_dev = (const fe *)dc; A.pool = d->pool; A.pool_cap = d->pool_cap; A.pool_stride = d->pool_stride;
-    const unsigned bs = d->block_size;
-    const dim3 grid((unsigned)(((d->Ti + bs - 1) / bs) * ntiles)), block(bs);
-    const bool l128 = d->layout == BSGS_TABLE_LINES128;
-    const size_t lds = (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048) + 16;
-    if (l128) hipLaunchKernelGGL((giant_pair2_kernel<3, false, true>), grid, block, lds, d->stream, A);
-    else      hipLaunchKernelGGL((giant_pair2_kernel<2, false, true>), grid, block, lds, d->stream, A);
-    HIPCHK(hipGetLastError());
-    return BSGS_OK;
 }
 
 // giants whose Gy trips the reference's NEGMODP (quirk mode): listed once per G2 upload
@@ -815,53 +752,20 @@ static int quirk_prepare(bsgs_dev *d)
     return BSGS_OK;
 }
 
-static bool lines_layout(const bsgs_dev *d) { return d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128; }
-
-// queue `ntiles` tiles whose centres are already in d->cen_dev[2*queued ...] (or, for the streamed / pooled variants that
-// keep their own buffers, in the host array `centres`)
-static int enqueue_common(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles)
+// queue `ntiles` tiles whose centres are already in d->cen_dev[2*queued ...]
+static int enqueue_common(bsgs_dev *d, uint32_t ntiles)
 {
-    const bool quirks = (d->flags & BSGS_FLAG_REFERENCE_QUIRKS) != 0;
-    if (quirks) { int rq = quirk_prepare(d); if (rq) return rq; }
-    const bool streamed = centres && !quirks && !d->digest && (d->variant >= 3 && d->variant <= 5) && lines_layout(d);
-    if (streamed) {
-        if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0)); d->timing_open = true; }
-        int rcs = launch_stream(d, centres, ntiles, d->queued);
-        if (rcs) return rcs;
-        d->launches++;
-        d->queued += ntiles;
-        return BSGS_OK;
-    }
-    const bool pooled = centres && !quirks && !d->digest && d->variant == 11 && (d->pi & 1u) == 0 && !d->debug_flags && !d->phase_probe && d->nstreams == 1 &&
-                        !d->tiles_per_launch && lines_layout(d);
-    if (pooled) {
-        if (!d->timing_open) { HIPCHK(hipEventRecord(d->ev0, d->stream)); HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0)); d->timing_open = true; }
-        static const uint32_t cap = getenv("BSGS_POOL_TILES") ? (uint32_t)std::max(1, atoi(getenv("BSGS_POOL_TILES"))) : 4096u;
-        for (uint32_t k = 0; k < ntiles; k += cap) {                      // one launch per `cap` tiles at most
-            const uint32_t n = std::min<uint32_t>(cap, ntiles - k);
-            int rcp = launch_pooled(d, centres + (size_t)k * 64, n, d->queued + k);
-            if (rcp) return rcp;
-            d->launches++;
-        }
-        d->queued += ntiles;
-        return BSGS_OK;
-    }
+    if (d->flags & BSGS_FLAG_REFERENCE_QUIRKS) { int rq = quirk_prepare(d); if (rq) return rq; }
     const uint32_t tpl = auto_tiles_per_launch(d);
     int rcc = ensure_chain(d, tpl);
     if (rcc) return rcc;
     if (!d->timing_open) {
         HIPCHK(hipEventRecord(d->ev0, d->stream));
-        HIPCHK(hipStreamWaitEvent(d->stream2, d->ev0, 0));     // stream2 starts after the timing origin (and after uploads)
         d->timing_open = true;
-    }
-    if (d->nstreams == 2) {                                    // the centres were written on the main stream
-        HIPCHK(hipEventRecord(d->evj, d->stream));
-        HIPCHK(hipStreamWaitEvent(d->stream2, d->evj, 0));
     }
     for (uint32_t k = 0; k < ntiles; k += tpl) {
         const uint32_t n = std::min<uint32_t>(tpl, ntiles - k);
-        const int which = d->nstreams == 2 ? (int)(d->launches & 1) : 0;
-        int rc = launch_tiles(d, d->cen_dev + 2 * (uint64_t)(d->queued + k), n, d->queued + k, which);
+        int rc = launch_tiles(d, d->cen_dev + 2 * (uint64_t)(d->queued + k), n, d->queued + k);
         if (rc) return rc;
         d->launches++;
     }
@@ -877,9 +781,9 @@ extern "C" int bsgs_prepare(bsgs_dev *d)
     if (!d->g2 || !d->layout) return fail(BSGS_ERR_STATE, "upload giants and table first");
     if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
     HIPCHK(hipSetDevice(d->id));
-    if ((d->variant >= 3 && d->variant <= 5) || d->variant == 11) return BSGS_OK;      // streamed / pooled variants keep their own scratch (13, 10, ... : the chain scratch below)
     int rc = ensure_chain(d, auto_tiles_per_launch(d));
     if (rc) return rc;
+    (void)pick_batching(d, 1);               // the narrow copy of the giants a one-tile launch takes (bsgs_step, route A before its centres are predictable), memory permitting
     HIPCHK(hipStreamSynchronize(d->stream));
     return BSGS_OK;
 }
@@ -895,7 +799,7 @@ extern "C" int bsgs_enqueue(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles
     uint8_t *pin = d->cen_pin + (size_t)d->queued * 64;       // a fresh region per enqueue: nothing queued is overwritten
     memcpy(pin, centres, (size_t)ntiles * 64);
     HIPCHK(hipMemcpyAsync(d->cen_dev + 2 * (uint64_t)d->queued, pin, (size_t)ntiles * 64, hipMemcpyHostToDevice, d->stream));
-    return enqueue_common(d, centres, ntiles);
+    return enqueue_common(d, ntiles);
 }
 
 // ---- device-side tile walk: replaces GetJob's host point addition + the per-launch upload (1_9_7File.pb:2077-2092, 2435-2445) ----
@@ -933,7 +837,7 @@ extern "C" int bsgs_enqueue_walk(bsgs_dev *d, uint64_t first_tile, uint32_t ntil
     hipLaunchKernelGGL(walk_centres_kernel, dim3((ntiles + 63) / 64), dim3(64), 0, d->stream, d->walk_p0x, d->walk_p0y,
                        (const fe *)d->walk_table, (u64)first_tile, (u32)ntiles, d->cen_dev + 2 * (uint64_t)d->queued, d->hitbuf + BSGS_HIT_WALK_STATUS);
     HIPCHK(hipGetLastError());
-    return enqueue_common(d, nullptr, ntiles);
+    return enqueue_common(d, ntiles);
 }
 
 extern "C" int bsgs_run_walk(bsgs_dev *d, uint64_t first_tile, uint32_t ntiles, bsgs_hit_ex *hits, uint32_t max_hits,
@@ -1021,7 +925,7 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
         }
         size_t best = 0;
         for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;      // a new placement has to win by 0.5 %
-        (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->stream2);
+        (void)hipStreamSynchronize(d->stream);
         for (size_t k = 0; k < held.size(); k++) if (k != best && held[k]) (void)hipFree(held[k]);
         d->chain = held[best];
         if (rc) return rc;
@@ -1051,7 +955,7 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
         }
         size_t best = 0;
         for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;
-        (void)hipStreamSynchronize(d->stream); (void)hipStreamSynchronize(d->stream2);
+        (void)hipStreamSynchronize(d->stream);
         for (size_t k = 0; k < held.size(); k++) if (k != best) (void)hipFree(held[k]);
         d->lines = held[best];
         if (rc) return rc;
@@ -1099,12 +1003,7 @@ extern "C" int bsgs_collect(bsgs_dev *d, bsgs_hit_ex *hits, uint32_t max_hits, u
 {
     if (!d) return fail(BSGS_ERR_ARG, "null");
     HIPCHK(hipSetDevice(d->id));
-    if (d->timing_open) {
-        HIPCHK(hipEventRecord(d->ev1, d->stream));
-        HIPCHK(hipEventRecord(d->ev2, d->stream2));
-    }
-    HIPCHK(hipEventRecord(d->evj, d->stream2));                 // join: the read-back below follows both streams
-    HIPCHK(hipStreamWaitEvent(d->stream, d->evj, 0));
+    if (d->timing_open) HIPCHK(hipEventRecord(d->ev1, d->stream));
     HIPCHK(hipMemcpyAsync(d->hit_host, d->hitbuf, 64, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     uint32_t n = d->hit_host[0];
@@ -1113,10 +1012,7 @@ extern "C" int bsgs_collect(bsgs_dev *d, bsgs_hit_ex *hits, uint32_t max_hits, u
     if (kernel_ms) {
         *kernel_ms = 0.f;
         if (d->timing_open) {
-            float a = 0.f, b = 0.f;
-            HIPCHK(hipEventElapsedTime(&a, d->ev0, d->ev1));
-            HIPCHK(hipEventElapsedTime(&b, d->ev0, d->ev2));
-            *kernel_ms = a > b ? a : b;
+            HIPCHK(hipEventElapsedTime(kernel_ms, d->ev0, d->ev1));
         }
     }
     d->timing_open = false;
@@ -1311,13 +1207,99 @@ extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
     return BSGS_OK;
 }
 
+// ---- replica verification -----------------------------------------------------------------------------------------------------
+// The reference gives every GPU its own upload from host memory (1_9_7File.pb:2337, 2350, 4769-4843); here replicas come from a
+// device-to-device copy (bsgs_broadcast_tables) or an RCCL broadcast (pybsgs.dist), and a replica that differs in one byte would lose keys
+// silently.  So every holder reduces what it holds to 64-bit checksums ON THE DEVICE (one pass at streaming rate: 16 GiB of lines in ~5 ms)
+// and the hosts compare them across engines / ranks (bsgs_mi355x -verifyreplicas, bench.py `table_checksum_equal`).
+//   position-dependent: sum over 64-bit words v at index i of mix(v + i * golden)   -- bucket lines, CSR image, giants
+//   position-independent: sum of mix(key) over the occupied slots                   -- the overflow hash set (slot order depends on insertion order)
+__device__ __forceinline__ u64 ck_mix(u64 z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+template <bool POSITIONAL>
+static __global__ void __launch_bounds__(256) checksum_kernel(const u64 *__restrict__ v, u64 n, const u32 *__restrict__ tail, unsigned long long *out)
+{
+    u64 acc = 0;
+    if (tail && blockIdx.x == 0 && threadIdx.x == 0) acc = ck_mix((u64)*tail + n * 0x9E3779B97F4A7C15ULL);      // a buffer of 8n + 4 bytes: its last 32-bit word
+    const u64 stride = (u64)gridDim.x * blockDim.x * 2;
+    for (u64 i = (blockIdx.x * (u64)blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
+        if (i + 1 < n) {
+            const ulonglong2 w = *(const ulonglong2 *)(v + i);          // 16 bytes per lane: one contiguous KiB per wave instruction
+            if (POSITIONAL) acc += ck_mix(w.x + i * 0x9E3779B97F4A7C15ULL) + ck_mix(w.y + (i + 1) * 0x9E3779B97F4A7C15ULL);
+            else acc += (w.x != BSGS_OVF_EMPTY ? ck_mix(w.x) : 0) + (w.y != BSGS_OVF_EMPTY ? ck_mix(w.y) : 0);
+        } else {
+            const u64 w = v[i];
+            if (POSITIONAL) acc += ck_mix(w + i * 0x9E3779B97F4A7C15ULL);
+            else acc += w != BSGS_OVF_EMPTY ? ck_mix(w) : 0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
+}
+static int checksum_of(bsgs_dev *d, const void *buf, uint64_t bytes, bool positional, unsigned long long *slot)
+{
+    if (!buf || bytes < 8) return BSGS_OK;
+    const u64 n = bytes / 8;
+    const u32 *tail = (bytes & 4) ? (const u32 *)buf + 2 * n : nullptr;   // the CSR image is (2^htsz + 1 + w) 32-bit words: possibly an odd number
+    const int blocks = (int)std::min<uint64_t>((n / 2 + 255) / 256, (uint64_t)d->prop.multiProcessorCount * 16);
+    if (positional) hipLaunchKernelGGL(checksum_kernel<true>, dim3(blocks), dim3(256), 0, d->stream, (const u64 *)buf, n, tail, slot);
+    else            hipLaunchKernelGGL(checksum_kernel<false>, dim3(blocks), dim3(256), 0, d->stream, (const u64 *)buf, n, tail, slot);
+    HIPCHK(hipGetLastError());
+    return BSGS_OK;
+}
+extern "C" int bsgs_table_checksum(bsgs_dev *d, uint64_t sums[4])
+{
+    if (!d || !sums) return fail(BSGS_ERR_ARG, "null");
+    if (!d->layout && !d->g2) return fail(BSGS_ERR_STATE, "nothing on the device");
+    HIPCHK(hipSetDevice(d->id));
+    unsigned long long *acc = nullptr;
+    HIPCHK(hipMalloc(&acc, 32));
+    int rc = BSGS_OK;
+    hipError_t e = hipMemsetAsync(acc, 0, 32, d->stream);
+    if (e == hipSuccess && d->layout) {
+        if (rc == BSGS_OK) rc = checksum_of(d, d->lines, d->lines ? d->lines_bytes : 0, true, acc + 0);
+        if (rc == BSGS_OK) rc = checksum_of(d, d->ovf, d->ovf_n * 8, false, acc + 1);
+        if (rc == BSGS_OK) rc = checksum_of(d, d->csr, d->csr ? 4 * (d->ht_items + 1) + 4 * d->w : 0, true, acc + 2);
+    }
+    if (e == hipSuccess && rc == BSGS_OK && d->g2) rc = checksum_of(d, d->g2, d->maxnonce * 64, true, acc + 3);
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, acc, 32, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void)hipFree(acc);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "table checksum: %s", hipGetErrorString(e));
+    for (int k = 0; k < 4; k++) sums[k] = h[k];
+    return BSGS_OK;
+}
+// test hook: flip bits of ONE byte of the installed table (bucket lines if the layout has them, else the CSR image) -- the corrupted replica
+// the verification must catch (tests/test_gpu_round4.py, bench.py BENCH_CORRUPT_RANK)
+extern "C" int bsgs_debug_corrupt_table(bsgs_dev *d, uint64_t byte_offset, uint32_t xor_mask)
+{
+    if (!d) return fail(BSGS_ERR_ARG, "null");
+    if (!d->layout) return fail(BSGS_ERR_STATE, "no table on device");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    uint8_t *base = d->lines ? (uint8_t *)d->lines : (uint8_t *)d->csr;
+    const uint64_t bytes = d->lines ? d->lines_bytes : 4 * (d->ht_items + 1) + 4 * d->w;
+    if (byte_offset >= bytes) return fail(BSGS_ERR_ARG, "offset %llu beyond the %llu bytes of the table", (unsigned long long)byte_offset, (unsigned long long)bytes);
+    HIPCHK(hipSetDevice(d->id));
+    uint8_t v = 0;
+    HIPCHK(hipMemcpy(&v, base + byte_offset, 1, hipMemcpyDeviceToHost));
+    v ^= (uint8_t)xor_mask;
+    HIPCHK(hipMemcpy(base + byte_offset, &v, 1, hipMemcpyHostToDevice));
+    return BSGS_OK;
+}
+
 // ---- phase timing: the same batch run with the kernel stopping after phase 1, after phase 2, and in full ------
 extern "C" int bsgs_profile_phases(bsgs_dev *d, const uint8_t *centres, uint32_t ntiles, float ms_out[3])
 {
     if (!d || !centres || !ms_out) return fail(BSGS_ERR_ARG, "null");
+    if (chain_group(d, d->pi) < 2) return fail(BSGS_ERR_STATE, "phase timing is an instrument of the chained kernel (bucket lines, even batch length)");
     const unsigned saved_flags = d->debug_flags;
-    const int saved_variant = d->variant;
-    if (d->variant >= 3 && d->variant <= 5) d->variant = 9;    // the per-tile kernels have separable phases
     const unsigned flags[3] = {1u, 2u, 0u};
     int rc = BSGS_OK;
     d->phase_probe = true;
@@ -1330,7 +1312,6 @@ extern "C" int bsgs_profile_phases(bsgs_dev *d, const uint8_t *centres, uint32_t
         }
     }
     d->debug_flags = saved_flags;
-    d->variant = saved_variant;
     d->phase_probe = false;
     return rc;
 }

@@ -15,19 +15,17 @@ int bsgs_fail(int code, const char *fmt, ...);
 
 struct bsgs_dev {
     int id = 0;
-    hipStream_t stream = nullptr;          // main stream: uploads, relayouts, even launches
-    hipStream_t stream2 = nullptr;         // odd launches: the next launch's blocks fill the tail of the previous one
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, evj = nullptr;
+    hipStream_t stream = nullptr;          // the engine's one stream: uploads, relayouts, tile launches, read-backs
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned debug_flags = 0;
     bool phase_probe = false;
-    unsigned block_size = 256;             // threads per workgroup of the tile kernel (BSGS_BLOCK: 64/128/256)
-    int nstreams = 1;                      // 2 = alternate launches over two streams (BSGS_STREAMS=2; faster on average, noisier)
+    unsigned block_size = 256;             // threads per workgroup of the tile kernel (four waves: one Fermat inversion per block)
     hipDeviceProp_t prop;
     // geometry
     uint32_t t = 0, b = 0, p = 0;          // the caller's geometry (file layout, hit index i = tid*p + j)
     uint64_t T = 0, maxnonce = 0;
     uint32_t Ti = 0, pi = 0;               // the engine's own: Ti threads x pi giants per inversion, Ti*pi = maxnonce
-    uint64_t chain_bytes = 0, chain_stride = 0;   // size of the chain scratch; u32x4 elements per stream
+    uint64_t chain_bytes = 0;              // size of the chain scratch
     // pair-batched kernel, one stream: the scratch in separately allocated, graded pieces of 2^chain_piece_log tiles (ensure_chain)
     std::vector<u32x4 *> chain_pieces;
     uint32_t chain_piece_log = 0;
@@ -41,10 +39,6 @@ struct bsgs_dev {
     uint32_t chain_from_reserve = 0;
     float chain_grade_best = 0.f, chain_grade_worst = 0.f;   // grade (G gathers/s) of the best / worst piece kept
     uint32_t chain_pad = 0;                       // extra u32x4 elements between the scratch areas of consecutive tiles
-    u32 *pool = nullptr;                   // pooled launches: per-XCD rings of free chain slots
-    uint32_t pool_cap = 0, pool_stride = 0, nxcc = 0;
-    u32x4 *schain = nullptr;               // streamed kernel: one scratch slot per resident block
-    uint64_t schain_blocks = 0;
     std::vector<void *> pending_dev, pending_pinned;   // per-enqueue centre buffers, released by bsgs_collect
     // buffers
     u32x4 *g2 = nullptr;        // [p][4][T]
@@ -53,9 +47,10 @@ struct bsgs_dev {
     // pattern is ONE tile per launch (1_9_7File.pb:2442-2459).  `narrow_off`: BSGS_NARROW_LAUNCHES=0 (A-B), or a layout that did not fit once.
     struct Batching { uint32_t Ti = 0, pi = 0; u32x4 *g2 = nullptr; };
     std::vector<Batching> narrow;
-    bool narrow_off = false;
+    bool narrow_off = false;               // this geometry's narrow copies did not fit once (reset by set_geometry / a table change)
+    bool narrow_env_off = false;           // BSGS_NARROW_LAUNCHES=0
     uint32_t last_Ti = 0, last_pi = 0;     // batching of the last tile launch (bsgs_debug_last_batching)
-    u32x4 *chain = nullptr;     // [stream][tile][p][2][T]
+    u32x4 *chain = nullptr;     // one-buffer scratch: [tile][p][2][T] (per-giant kernel) or the chained kernel's layout when not in pieces
     u32 *csr = nullptr;         // htGPU image
     bool csr_owned = true;
     u32x4 *lines = nullptr;
@@ -71,12 +66,9 @@ struct bsgs_dev {
     uint32_t tiles_per_launch = 0;         // 0 = automatic (fill the chip: Ti * tiles >= 1024 threads per CU)
     uint32_t auto_tpl = 0;                 // the automatic choice, made once the giants and the table are resident (memory permitting: 4x)
     uint64_t launches = 0;
-    int variant = 13;           // BSGS_KERNEL_VARIANT (all bit-identical): 13 (default) = 10 with ONE stored product per FOUR giants and one probe in flight per wave
-                                // (falls back to 10 when the engine's batch length is not a multiple of 4); per-tile kernels 0 synchronous probes, 1 pipelined probes,
-                                // 2 early / 7 late prefetch, 8 = 7 + LDS-staged probe, 9 = both probes LDS-staged, 6 pair-batched chain,
-                                // 10 = 9 + pair-batched chain (default; falls back to 9 for an odd chain length), 11 = 10 as ONE launch
-                                // per queue with pooled chain scratch (slower sustained: DESIGN.md 8); streamed ping-pong
-                                // kernels 3, 4 (LDS probes), 5 (all loads LDS-staged, counted vmcnt)
+    int variant = 13;           // BSGS_KERNEL_VARIANT (A-B and tests; all bit-identical): 13 (default) = chained kernel, one stored product per FOUR giants, one probe
+                                // in flight per wave (falls back to 10 when the engine's batch length is not a multiple of 4); 10 = one stored product per PAIR, two
+                                // probes in flight; 0 = the per-giant kernel (also taken for the CSR layout and for odd batch lengths)
     bool timing_open = false;
     // tile centres of the queued launches, device + pinned staging (grow-only; replaced buffers wait in pending_* for bsgs_collect)
     fe *cen_dev = nullptr;
@@ -114,6 +106,9 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes);    
 template <typename T> static inline hipError_t bsgs_big_malloc(T **p, size_t bytes) { return bsgs_big_malloc((void **)p, bytes); }
 
 // shared between the translation units of the library
+// tile_lines64.hip / tile_lines128.hip: the tile-kernel instantiations per bucket-line size (tile_launch.inc)
+hipError_t bsgs_launch_tile_lines64(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
+hipError_t bsgs_launch_tile_lines128(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
 void bsgs_free_table(bsgs_dev *d);
 void bsgs_free_recv(bsgs_dev *d);                            // receive buffers that were never installed
 uint64_t bsgs_ovf_slots(uint64_t entries);                   // size of the overflow hash set for `entries` keys (power of two, load <= 1/2)

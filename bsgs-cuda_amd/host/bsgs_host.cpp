@@ -80,6 +80,7 @@ struct Config {
     uint64_t max_tiles = 0;                        // test hook: stop after this many tiles (0 = unlimited)
     bool ext = false;                              // extended table (bucket lines + overflow list, no HT files); implied by w >= 3069485951
     std::string dir = ".";                         // where table / output files live
+    bool verify_replicas = true;                   // several engines: compare table checksums and the hits of one tile across them before searching (-noverify skips)
     bool ref_quirks = false;                       // -refquirks: reproduce the reference kernel's NEGMODP bug bit for bit (BSGS_FLAG_REFERENCE_QUIRKS)
     bool host_centres = false;                     // -hostcentres: tile centres added on the host and uploaded (the reference's way) instead of the device walk
     bool tune = false;                             // -tune: also choose the bucket-line placement by measurement at start-up (bsgs_tune_placement)
@@ -107,6 +108,7 @@ static void usage(const Config &c)
            "-wl      Set recovery file from which the state will be loaded\n-wt      Set timer for autosaving current state, default every %dseconds\n"
            "-onlygen Generate the table files and exit (onlygen_1_9_6File0.exe)\n-dir     Directory for table files, currentwork.txt and win.txt\n"
            "-ext     Extended baby table built in GPU memory (no HT files); automatic for -w above the reference limit, up to 2^36\n"
+           "-noverify    Several GPUs: skip the comparison of the replicas (table checksums, one probe tile) after they were made\n"
            "-refquirks   Reproduce the reference kernel's -Gy borrow bug bit for bit (default: correct arithmetic, finds a superset)\n"
            "-hostcentres Add the tile centres on the host and upload them (default: derived on the GPU from the tile counter)\n"
            "-tune        Time a few placements of the GPU buffers at start-up and keep the fastest (the engine already places them by grade)\n",
@@ -144,6 +146,8 @@ static Config parse_args(int argc, char **argv)
         else if (a == "-dir") c.dir = next();
         else if (a == "-ext") c.ext = true;
         else if (a == "-refquirks") c.ref_quirks = true;
+        else if (a == "-verifyreplicas") c.verify_replicas = true;
+        else if (a == "-noverify") c.verify_replicas = false;
         else if (a == "-hostcentres") c.host_centres = true;
         else if (a == "-tune") c.tune = true;
         else if (a == "-joblog") c.joblog = next();
@@ -454,6 +458,42 @@ static void load_first(const Shared &S, int gpu, bsgs_dev *dev, const std::vecto
         printf("GPU #%d extended table: %llu items, %.1f GiB in memory, %llu over-full buckets, built in %.1fs\n", gpu, (unsigned long long)S.cfg.w,
                bytes / 1073741824.0, (unsigned long long)ovf, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     } else CK(bsgs_upload_htgpu(dev, htgpu.data(), 1ull << S.cfg.htsz, S.cfg.w, BSGS_TABLE_AUTO));
+}
+
+// A replica that differs from the first engine's tables in one byte loses keys silently.  The reference uploads every GPU from ONE host buffer
+// (1_9_7File.pb:2337, 2350, 4769-4843); ours travelled device-to-device, so they are compared before the search starts: the 64-bit checksums
+// each engine computes over what it holds (bsgs_table_checksum), and the complete hit list of one probe tile run on every engine.
+static void verify_replicas(const std::vector<int> &gpus, const std::vector<bsgs_dev *> &devs)
+{
+    if (const char *e = getenv("BSGS_TEST_CORRUPT_ENGINE")) {         // test hook: one flipped bit in one engine's table must stop the run
+        const size_t k = (size_t)atoi(e);
+        if (k < devs.size()) CK(bsgs_debug_corrupt_table(devs[k], 4096 + 5, 0x10));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::array<uint64_t, 4>> sums(devs.size());
+    for (size_t gi = 0; gi < devs.size(); gi++) CK(bsgs_table_checksum(devs[gi], sums[gi].data()));
+    uint8_t centre[64];
+    hs::affine_to_le(hs::point_mul(hs::G, hs::fe_from_u64(0x5EEDC0FFEEull)), centre, centre + 32);
+    std::vector<std::vector<bsgs_hit_ex>> hits(devs.size(), std::vector<bsgs_hit_ex>(65536));
+    std::vector<uint32_t> nh(devs.size(), 0);
+    for (size_t gi = 0; gi < devs.size(); gi++) {
+        const int rc = bsgs_run(devs[gi], centre, 1, hits[gi].data(), (uint32_t)hits[gi].size(), &nh[gi], nullptr);
+        if (rc != BSGS_OK && rc != BSGS_ERR_OVERFLOW) die(std::string("replica verification: ") + bsgs_last_error());
+        hits[gi].resize(std::min<uint32_t>(nh[gi], 65536));
+    }
+    for (size_t gi = 1; gi < devs.size(); gi++) {
+        if (sums[gi] != sums[0]) {
+            static const char *what[4] = {"bucket lines", "overflow set", "htGPU image", "giants"};
+            for (int k = 0; k < 4; k++) if (sums[gi][k] != sums[0][k])
+                fprintf(stderr, "GPU #%d engine %zu: checksum of the %s is %016llx, engine 0 has %016llx\n", gpus[gi], gi, what[k], (unsigned long long)sums[gi][k], (unsigned long long)sums[0][k]);
+            die("replica verification FAILED: the tables of GPU #" + std::to_string(gpus[gi]) + " differ from the first engine's");
+        }
+        if (nh[gi] != nh[0] || memcmp(hits[gi].data(), hits[0].data(), hits[0].size() * sizeof(bsgs_hit_ex)) != 0)
+            die("replica verification FAILED: GPU #" + std::to_string(gpus[gi]) + " reports other hits than the first engine for the same tile");
+    }
+    printf("Replica verification: %zu engines hold identical tables (lines %016llx, overflow set %016llx, image %016llx, giants %016llx), probe tile: %u hits on each, in %.2fs\n",
+           devs.size(), (unsigned long long)sums[0][0], (unsigned long long)sums[0][1], (unsigned long long)sums[0][2], (unsigned long long)sums[0][3], nh[0],
+           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
 }
 
 static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
@@ -770,6 +810,7 @@ int main(int argc, char **argv)
             CK(bsgs_broadcast_tables(devs.data(), (int)devs.size()));
             printf("Tables replicated to %zu more GPU engine(s) device-to-device in %.2fs\n", devs.size() - 1, std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
             for (size_t gi = 1; gi < devs.size(); gi++) prepare(gi);
+            if (c.verify_replicas) verify_replicas(gpus, devs);
         }
         (void)t0;
         if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }

@@ -18,14 +18,14 @@ FLAG_REFERENCE_QUIRKS = 1
 
 # every symbol include/bsgs_hip.h declares (checked by tests/test_abi.py)
 NATIVE_SYMBOLS = [
-    "bsgs_last_error", "bsgs_version", "bsgs_dev_count", "bsgs_dev_open", "bsgs_dev_close", "bsgs_dev_name",
+    "bsgs_last_error", "bsgs_version", "bsgs_build_info", "bsgs_dev_count", "bsgs_dev_open", "bsgs_dev_close", "bsgs_dev_name",
     "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
     "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_debug_xcd_profile",
-    "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
+    "bsgs_table_checksum", "bsgs_debug_corrupt_table", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -85,6 +85,7 @@ def lib():
         vp, u8p = C.c_void_p, C.c_char_p
         L.bsgs_last_error.restype = C.c_char_p
         L.bsgs_version.restype = C.c_char_p
+        L.bsgs_build_info.restype = C.c_char_p
         sig = {
             "bsgs_dev_count": [C.POINTER(C.c_int)],
             "bsgs_dev_open": [C.c_int, C.POINTER(vp)],
@@ -119,6 +120,8 @@ def lib():
             "bsgs_install_table_ext_device": [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32],
             "bsgs_alloc_table_ext_recv": [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)],
             "bsgs_debug_last_kernel": [vp, C.c_char_p, C.c_int],
+            "bsgs_table_checksum": [vp, C.POINTER(C.c_uint64)],
+            "bsgs_debug_corrupt_table": [vp, C.c_uint64, C.c_uint32],
             "bsgs_debug_table_owner": [vp, C.POINTER(C.c_int)],
             "bsgs_prepare": [vp],
             "bsgs_profile_phases": [vp, u8p, C.c_uint32, C.POINTER(C.c_float)],
@@ -154,6 +157,11 @@ def _chk(rc, allow_overflow=False):
 
 def le32(v):
     return int(v).to_bytes(32, "little")
+
+
+def build_info():
+    """the -D switches the loaded library was built with ("" = the shipped build; "WRONG-RESULTS:..." = a timing experiment)"""
+    return lib().bsgs_build_info().decode()
 
 
 def broadcast_tables(devices):
@@ -265,6 +273,16 @@ class Device:
 
     def prepare(self):
         _chk(self.L.bsgs_prepare(self.h))
+
+    def table_checksum(self):
+        """device-side 64-bit checksums of (bucket lines, overflow set, CSR image, giants): equal across byte-identical replicas"""
+        s = (C.c_uint64 * 4)()
+        _chk(self.L.bsgs_table_checksum(self.h, s))
+        return [int(x) for x in s]
+
+    def debug_corrupt_table(self, byte_offset, xor_mask=1):
+        """test hook: flip bits of one byte of the installed table (what replica verification must catch)"""
+        _chk(self.L.bsgs_debug_corrupt_table(self.h, byte_offset, xor_mask))
 
     def table_owned(self):
         v = C.c_int()

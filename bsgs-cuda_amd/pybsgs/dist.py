@@ -91,6 +91,16 @@ def gather_objects(obj):
     return out
 
 
+def all_equal(obj):
+    """(does every rank hold an equal object?, every rank's object in rank order) -- replica verification: table checksums, the hit list of a
+    launch every rank ran (bench.py; the C++ host compares its engines the same way after bsgs_broadcast_tables)"""
+    objs = gather_objects(obj)
+    return all(o == objs[0] for o in objs), objs
+
+
+XGMI_LINK_GBPS = 153.0        # one xGMI link of an MI355X (7 per GPU): what a one-to-all broadcast out of rank 0 can use per destination
+
+
 def barrier(cuda=True):
     if not _alone():
         td.barrier()

@@ -59,6 +59,22 @@ def test_product_does_not_link_or_import_the_oracle(libpath):
                 assert "liboracle" not in src and "oracle_lib" not in src and "curve64_ref" not in src, f
 
 
+def test_shipped_library_has_no_experiment_switch_and_ceilings_need_one(libpath, tmp_path):
+    """bsgs_build_info() of the library the tests (and the driver) load is empty: no A/B switch, above all none of the *_CEILING timing
+    experiments, which return wrong results; and such a switch does not compile without -DBSGS_EXPERIMENT"""
+    L = ctypes.CDLL(libpath)
+    L.bsgs_build_info.restype = ctypes.c_char_p
+    assert L.bsgs_build_info() == b"", L.bsgs_build_info()
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "guard.hip"
+    src.write_text('#include "%s"\n' % os.path.join(ROOT, "bsgs-cuda_amd", "csrc", "giant_kernel.hip.h"))
+    for sw in ("BSGS_NOCHAIN_CEILING", "BSGS_G2_CACHED_CEILING", "BSGS_NO_OVF_CEILING"):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-D" + sw, str(src)], capture_output=True, text=True)
+        assert r.returncode != 0 and "BSGS_EXPERIMENT" in r.stderr, (sw, r.stderr[-300:])
+
+
 def test_narrow_batching_rule(libpath):
     """bsgs_debug_narrow_batching = the rule a launch's batching follows (bsgs_hip.hip narrow_pi), no device needed: a launch of few tiles halves
     the giants per thread until it has four blocks of 256 threads per CU, never below 128, never to an odd or non-multiple-of-4 batch, never to a

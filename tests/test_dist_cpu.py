@@ -35,6 +35,11 @@ D.barrier(cuda=False)
 # what bench.py --dump-hits gathers: every rank's record, in rank order, on every rank
 recs = D.gather_objects({"rank": rank, "tiles": [k for k, _ in mine], "nhits": len(hits)})
 assert [r["rank"] for r in recs] == list(range(world)) and recs[rank]["nhits"] == len(hits)
+# replica verification (bench.py): equal objects on every rank -> True everywhere; one rank differing in one value -> False everywhere
+import hashlib
+same, sums = D.all_equal([hashlib.sha256(table).hexdigest(), len(g2)])
+bad, _ = D.all_equal([hashlib.sha256(table).hexdigest(), len(g2) + (1 if rank == 1 else 0)])
+assert same and not bad and len(sums) == world and D.XGMI_LINK_GBPS > 100
 steps = D.reduce_sum_int(len(mine) * 2 * fx["t"] * fx["b"] * fx["p"])
 tmax = D.reduce_max([0.5 + rank])[0]
 json.dump({"rank": rank, "world": world, "gathered": recs, "hits": hits, "tiles": [k for k, _ in mine], "steps": steps, "tmax": tmax},

@@ -339,20 +339,20 @@ def test_cuda_compat_layer_runs_a_tile(small_fx):
     assert L.cuCtxDestroy_v2(ctx) == 0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13])
-@pytest.mark.parametrize("streams", [1, 2])
-def test_all_kernel_variants_agree_with_oracle(O, small_fx, variant, streams):
-    """every kernel variant (per-tile 0-2, streamed 3-5; one or two HIP streams) returns the oracle's hit lists:
-    many tiles per call, so the streamed kernels walk sequences in both directions"""
+@pytest.mark.parametrize("variant,kernel", [(13, "giant_pair2_kernel<2, false, true>"), (10, "giant_pair2_kernel<2, false, false>"), (0, "giant_tile_kernel<2>")])
+def test_all_kernel_variants_agree_with_oracle(O, small_fx, variant, kernel):
+    """the three tile kernels of the library -- chained, one stored product per four giants (the default); chained, one per pair; the per-giant
+    fallback -- return the oracle's hit lists, many tiles per call; anything else in BSGS_KERNEL_VARIANT is refused"""
     import os
     import pybsgs
-    if streams == 2 and variant in (3, 4, 5):
-        pytest.skip("streamed kernels use one launch per batch")
-    os.environ["BSGS_KERNEL_VARIANT"], os.environ["BSGS_STREAMS"] = str(variant), str(streams)
+    os.environ["BSGS_KERNEL_VARIANT"] = "9"
     try:
+        with pytest.raises(pybsgs.BsgsError):
+            pybsgs.Device(0)
+        os.environ["BSGS_KERNEL_VARIANT"] = str(variant)
         d = pybsgs.Device(0)
     finally:
-        del os.environ["BSGS_KERNEL_VARIANT"], os.environ["BSGS_STREAMS"]
+        del os.environ["BSGS_KERNEL_VARIANT"]
     t, b, p, w, htsz = 64, 8, 12, 1 << 16, 14                       # T = 512: two 256-thread slices
     g2, gpu, centres = _planted_case(O, 4242, t, b, p, w, htsz, 12, 9)
     centres = centres + [O.pt_mul(k) for k in (5, 70000)] + [O.g2_unpack(g2, t, b, p, 77)]     # code 5 twice, an x-equal tile
@@ -364,6 +364,7 @@ def test_all_kernel_variants_agree_with_oracle(O, small_fx, variant, streams):
         r, _ = O.tile_ref(Pt, g2, t, b, p, gpu, htsz, 0, 65536)
         ref_all += [(k, c, i) for c, i in r]
     assert n == len(ref_all) and hits == ref_all
+    assert d.last_kernel() == kernel
     # fixture tiles one at a time (sequence length 1)
     fx = small_fx
     d.upload_g2(bytes.fromhex(fx["g2"]), fx["t"], fx["b"], fx["p"])

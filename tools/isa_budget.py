@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Static instruction budget of the hot loop of giant_pair2_kernel<2, false, false, true> (the default tile kernel: quad chain; ISA_KERNEL=..ELb0EEv8TileArgs for the pair chain).
+"""Static instruction budget of the hot loop of giant_pair2_kernel<2, false, true> (the default tile kernel: quad chain; ISA_KERNEL=..ELb0EEv8TileArgs for the pair chain).
 
   tools/isa_budget.py [out.json]      (needs hipcc; cross-compiles for gfx950, no GPU)
 
-Compiles csrc/bsgs_hip.hip to ISA, finds the probe loop (the largest loop of the kernel), and classifies every basic block of it:
+Compiles csrc/tile_lines64.hip to ISA, finds the probe loop (the largest loop of the kernel), and classifies every basic block of it:
   M    a 256x256-bit multiplication with its fold (>= 60 v_mad_u64_u32)
   S    the low-64-bit squaring path (20..59 multiply-adds)
   glue everything else on the main path (field additions, probe issue / compare, addressing, loop control)
@@ -24,7 +24,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = os.environ.get("ISA_KERNEL", "_Z18giant_pair2_kernelILi2ELb0ELb0ELb1EEv8TileArgs")
+KERNEL = os.environ.get("ISA_KERNEL", "_Z18giant_pair2_kernelILi2ELb0ELb1EEv8TileArgs")
 COST = {"mad64": 4.2, "carry": 4.1, "plain": 2.3}
 
 
@@ -40,7 +40,7 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else None
     asm = "/tmp/bsgs_isa_budget.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", *os.environ.get("ISA_DEFS", "").split(), "-S", "--cuda-device-only", "-o", asm,
-                           os.path.join(ROOT, "bsgs-cuda_amd", "csrc", "bsgs_hip.hip")], stderr=subprocess.DEVNULL)
+                           os.path.join(ROOT, "bsgs-cuda_amd", "csrc", "tile_lines64.hip")], stderr=subprocess.DEVNULL)
     text = open(asm).read()
     lines = text.split("\n")
     a = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
@@ -104,7 +104,7 @@ def main():
         for n, v in c.items():
             if n.startswith("v_"):
                 d[group(n)] += v
-    res = {"kernel": "giant_pair2_kernel<2, false, false, true>" if KERNEL.endswith("ELb1EEv8TileArgs") else "giant_pair2_kernel<2, false, false, false>", "vgprs": int(vgpr.group(1)) if vgpr else None,
+    res = {"kernel": "giant_pair2_kernel<2, false, true>" if KERNEL.endswith("ELb1EEv8TileArgs") else "giant_pair2_kernel<2, false, false>", "vgprs": int(vgpr.group(1)) if vgpr else None,
            "loop": "one iteration = four giants = 8 giant steps (quad chain) or one pair of giants = 4 giant steps (pair chain); two x coordinates per giant",
            "cost_cycles_per_wave_instruction": COST, "classes": {}}
     for kind, d in classes.items():

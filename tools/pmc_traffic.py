@@ -20,7 +20,7 @@ def rows(path):
 
 
 import re
-PROD = re.compile(r"giant_pair2_kernel<\d, false, false(, (true|false))?>")      # production instantiations (PHASE_PROBE = false, POOL = false)
+PROD = re.compile(r"giant_pair2_kernel<\d, false, (true|false)>")      # production instantiations (PHASE_PROBE = false)
 
 
 def pick(d, counter, kernel_sub, exclude=None):
