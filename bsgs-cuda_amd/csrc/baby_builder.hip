@@ -311,9 +311,11 @@ extern "C" int bsgs_install_table_ext_device(bsgs_dev *d, const void *lines_dev,
     if (ovf_n < 2 || (ovf_n & (ovf_n - 1))) return fail(BSGS_ERR_ARG, "ovf_n must be the slot count returned by the builder (a power of two)");
     HIPCHK(hipSetDevice(d->id));
     const bool mine = d->recv_lines && lines_dev == d->recv_lines && ovf_dev == d->recv_ovf;    // bsgs_alloc_table_ext_recv's buffers
-    if (mine) { d->recv_lines = nullptr; d->recv_ovf = nullptr; }                                  // (install_lines frees the previous table, not these)
+    // (install_lines frees the previous TABLE, never the receive buffers; they change hands only once the install succeeded: a refused table
+    // leaves them with bsgs_free_recv / bsgs_dev_close)
     rc = bsgs_install_lines(d, (u32x4 *)lines_dev, layout == BSGS_TABLE_LINES128_LIST ? 3 : 2, (u64 *)ovf_dev, ovf_n, 1ull << htsz, w, overflow_buckets);
     if (rc) return rc;
+    if (mine) { d->recv_lines = nullptr; d->recv_ovf = nullptr; }
     d->lines_owned = mine;                                            // otherwise borrowed: the caller keeps both buffers alive
     return BSGS_OK;
 }

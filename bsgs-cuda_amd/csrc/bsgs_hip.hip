@@ -464,6 +464,7 @@ extern "C" int bsgs_generate_g2(bsgs_dev *d, const uint8_t a_xy_le[64], uint32_t
 }
 
 // ---- baby table -----------------------------------------------------------------------------------------
+static int validate_ext_table(bsgs_dev *d, const u32x4 *lines, int lplog, const u64 *ovf, uint64_t ovf_n, uint64_t ht_items);
 // with_list: the entries that do not fit go to a sorted overflow list and the CSR image is dropped afterwards
 static int build_lines(bsgs_dev *d, uint32_t layout, bool with_list)
 {
@@ -495,6 +496,8 @@ static int build_lines(bsgs_dev *d, uint32_t layout, bool with_list)
         int rc = bsgs_ovf_fill(d, list, cap, table, slots);
         (void)hipFree(list);
         if (rc) { (void)hipFree(table); return rc; }
+        rc = validate_ext_table(d, d->lines, lplog, table, slots, d->ht_items);      // an image with unsorted buckets (not the reference's format) ends here
+        if (rc) { (void)hipFree(table); (void)hipFree(d->lines); d->lines = nullptr; d->layout = 0; return rc; }
         d->ovf = table; d->ovf_n = slots;
         if (d->csr && d->csr_owned) (void)hipFree(d->csr);
         d->csr = nullptr;                                               // borrowed images stay with the caller
@@ -521,9 +524,36 @@ int bsgs_ovf_fill(bsgs_dev *d, const u64 *list, uint64_t n, u64 *table, uint64_t
     return BSGS_OK;
 }
 
+// the invariant the probe's overflow-bound shortcut rests on (giant_kernel.hip.h: ext_validate_*): checked for every lines + overflow-set table
+static int validate_ext_table(bsgs_dev *d, const u32x4 *lines, int lplog, const u64 *ovf, uint64_t ovf_n, uint64_t ht_items)
+{
+    unsigned long long *bad = nullptr, h[2] = {0, 0};
+    HIPCHK(hipMalloc(&bad, 16));
+    hipError_t e = hipMemsetAsync(bad, 0, 16, d->stream);
+    const int lb = (int)std::min<uint64_t>((ht_items + 255) / 256, 1u << 16), sb = (int)std::min<uint64_t>((ovf_n + 255) / 256, 1u << 16);
+    if (lplog == 3) {
+        hipLaunchKernelGGL(ext_validate_lines_kernel<3>, dim3(lb), dim3(256), 0, d->stream, (const u32 *)lines, ht_items, bad);
+        hipLaunchKernelGGL(ext_validate_set_kernel<3>, dim3(sb), dim3(256), 0, d->stream, (const u32 *)lines, ht_items, ovf, ovf_n, bad);
+    } else {
+        hipLaunchKernelGGL(ext_validate_lines_kernel<2>, dim3(lb), dim3(256), 0, d->stream, (const u32 *)lines, ht_items, bad);
+        hipLaunchKernelGGL(ext_validate_set_kernel<2>, dim3(sb), dim3(256), 0, d->stream, (const u32 *)lines, ht_items, ovf, ovf_n, bad);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, bad, 16, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "table validation: %s", hipGetErrorString(e));
+    if (h[0] || h[1])
+        return fail(BSGS_ERR_ARG, "this lines + overflow-set table breaks the overflow bound (%llu over-full lines hold an entry above their last word, %llu keys of the set are "
+                                  "below their line's last word or belong to no over-full line): a probe would miss entries.  Build it with bsgs_build_baby_table_ext*, or "
+                                  "from an htGPU image whose buckets are sorted ascending", h[0], h[1]);
+    return BSGS_OK;
+}
+
 int bsgs_install_lines(bsgs_dev *d, u32x4 *lines, int lplog, u64 *ovf, uint64_t ovf_n, uint64_t ht_items, uint64_t w,
                        uint64_t overflow_buckets)
 {
+    if (ovf) { int rc = validate_ext_table(d, lines, lplog, ovf, ovf_n, ht_items); if (rc) return rc; }
     free_table(d);
     d->lines = lines; d->lines_bytes = ht_items * (64ull << (lplog - 2));
     d->ovf = ovf; d->ovf_n = ovf_n;

@@ -64,7 +64,8 @@ def _bench(args, env_extra=None, timeout=1500, expect_rc=0):
     env = dict(os.environ)
     env.update(env_extra or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
-    assert r.returncode == expect_rc, (r.returncode, r.stdout[-3000:] + r.stderr[-3000:])
+    # (ranks exit with 3 on a failed verification; torch.distributed.run reports any failed rank as 1)
+    assert (r.returncode != 0) if expect_rc == "nonzero" else (r.returncode == expect_rc), (r.returncode, r.stdout[-3000:] + r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     return json.loads(lines[0])
@@ -76,7 +77,7 @@ def test_bench_turns_red_when_rank_1_holds_a_corrupted_replica(table):
     non-zero exit code, no rate, and say which rank differs"""
     common = ["--w", "26", "--htsz", "25", "--tiles-per-launch", "48", "--steps", "2", "--warmup", "1", "--warmup-s", "0", "--sustain-s", "0",
               "--no-cpu-baseline", "--no-solve", "--no-pmc", "--gpus", "2", "--same-device"] + (["--force-ext"] if table == "extended" else [])
-    bad = _bench(common, env_extra={"BENCH_CORRUPT_RANK": "1"}, expect_rc=3)
+    bad = _bench(common, env_extra={"BENCH_CORRUPT_RANK": "1"}, expect_rc="nonzero")
     assert bad["value"] is None and bad["error"] == "replica verification FAILED" and bad["ranks_differing_from_rank0"] == [1]
     assert bad["verification"]["table_checksum_equal"] is False
     assert bad["checksums_per_rank"][0][0] != bad["checksums_per_rank"][1][0] and bad["checksums_per_rank"][0][3] == bad["checksums_per_rank"][1][3]
@@ -97,3 +98,42 @@ def test_host_verifies_replicas_and_stops_on_a_corrupted_one(tmp_path):
     assert bad.returncode != 0 and "replica verification FAILED" in (bad.stdout + bad.stderr) and "KEY[1]" not in bad.stdout
     skip = subprocess.run(args + ["-noverify"], capture_output=True, text=True, timeout=600, env=dict(os.environ, BSGS_TEST_CORRUPT_ENGINE="1"))
     assert skip.returncode == 0 and "Replica verification" not in skip.stdout
+
+
+def test_overflow_bound_invariant_is_checked_at_install(O):
+    """the probe never looks into the overflow set for a hash below an over-full line's last word, so a lines + overflow-set table
+    that does not keep its smallest hashes in the line would miss hits silently.  Such a table is refused: (i) a built table whose one line's
+    bound was raised; (ii) an htGPU image whose buckets are NOT sorted, asked for in a LIST layout -- which the exact layouts still search."""
+    import torch
+    import pybsgs
+    from test_gpu_round2 import _random_table
+    w, htsz, lay = 1 << 16, 10, pybsgs.TABLE_LINES64_LIST           # 64 per bucket: every 64-byte line is over-full
+    dev = pybsgs.Device(0)
+    cap = dev.ext_overflow_capacity(w, htsz, lay)
+    lines = torch.empty((1 << htsz) * 16, dtype=torch.int32, device="cuda:0")
+    ovf = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+    n_ovf, n_over = dev.build_baby_table_ext_device(w, htsz, lay, lines.data_ptr(), ovf.data_ptr(), cap)
+    assert n_over == 1 << htsz
+    dev.install_table_ext_device(lines.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)      # as built: accepted
+    keep = int(lines[16 * 77 + 15])
+    lines[16 * 77 + 15] = -1                                         # line 77: last word 0xFFFFFFFF -> its set entries are now "below the bound"
+    torch.cuda.synchronize()
+    with pytest.raises(pybsgs.BsgsError, match="overflow bound"):
+        dev.install_table_ext_device(lines.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
+    lines[16 * 77 + 15] = keep
+    lines[16 * 5 + 3] = -1                                           # line 5: an entry above its last word
+    torch.cuda.synchronize()
+    with pytest.raises(pybsgs.BsgsError, match="overflow bound"):
+        dev.install_table_ext_device(lines.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
+    # (ii) an image with one bucket's hashes reversed
+    import numpy as np
+    gpu = _random_table(O, random.Random(3), w, 12, [])              # 16 per bucket at htsz 12
+    img = np.frombuffer(gpu, dtype=np.uint32).copy()
+    items = 1 << 12
+    bkt = next(k for k in range(items) if int(img[k + 1]) - int(img[k]) >= 18)       # an over-full bucket (more than the 15 entries of a line)
+    lo, hi = int(img[bkt]), int(img[bkt + 1])
+    img[items + 1 + lo: items + 1 + hi] = img[items + 1 + lo: items + 1 + hi][::-1]
+    with pytest.raises(pybsgs.BsgsError, match="overflow bound"):
+        dev.upload_htgpu(img.tobytes(), items, w, pybsgs.TABLE_LINES64_LIST)
+    dev.upload_htgpu(gpu, items, w, pybsgs.TABLE_LINES64_LIST)      # the sorted image: fine
+    dev.close()
