@@ -14,20 +14,55 @@
 #include "host_secp.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
-// keys[j*T + tid] = low 64 bits of x((first + j*T + tid) * G); only indices < count are written
-__global__ void __launch_bounds__(256) baby_keys_kernel(const u32x4 *__restrict__ helper, const u32x4 *__restrict__ bases,
-                                                        u64 *__restrict__ keys, u32x4 *__restrict__ chain, u32 T, u32 pi, u64 count)
+// Point generation: thread tid walks S_tid + j*(T*G), S_tid = (first + tid)*G, j = 0..pi-1, with the tile kernel's batched inverse over its pi
+// points, and hands the 64-bit key (low 64 bits of x) of point number first + j*T + tid to a SINK:
+//   SINK 0: keys[j*T + tid] = bucket << 32 | hash, pos[j*T + tid] = its position (the reference-format images need the positions: sorted next);
+//   SINK 2 / 3: straight into 64 / 128-byte bucket lines (ext_scatter_kernel's claim-a-slot atomic, fused: no key array, and the memory-bound
+//   scatter overlaps with the arithmetic of the other waves).  The slot an atomic returns is used one point LATER, so the wave never waits for it.
+// Only indices < count are produced.  helper[j-1] = j*(T*G) (uniform: scalar loads); chain = [pi][2][T] scratch.
+struct KeySink {
+    u64 *keys; u32 *pos; u32 pos_base;  // SINK 0: sort key (bucket << 32 | hash) and position of point number idx (197:2561, 2583, 1221)
+    u32 *lines; u64 *ovf; u64 ovf_cap; unsigned long long *counters; u32 mask;      // SINK 2 / 3 (as ext_scatter_kernel)
+};
+template <int SINK>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) baby_keys_kernel(const u32x4 *__restrict__ helper, const u32x4 *__restrict__ bases, const KeySink K,
+                                                        u32x4 *__restrict__ chain, u32 T, u32 pi, u64 count)
 {
+    constexpr u32 WORDS = SINK == 3 ? 32u : 16u, CAP = WORDS - 1;
     const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= T) return;
+    u32 *pend_line = nullptr;          // the claim whose slot number is still in flight
+    u32 pend_slot = 0, pend_hash = 0;
+    u64 pend_bucket = 0;
+    auto settle = [&]() {
+        if (SINK == 0 || !pend_line) return;
+        if (pend_slot < CAP - 1) pend_line[1 + pend_slot] = pend_hash;             // CAP - 1 arrivals in the line; word CAP is the bound (ext_refine_kernel)
+        else {
+            const u64 at = atomicAdd(K.counters + 1, 1ull);
+            if (at < K.ovf_cap) K.ovf[at] = (pend_bucket << 32) | pend_hash;
+        }
+        pend_line = nullptr;
+    };
+    auto emit = [&](u64 idx, u64 key) {
+        if (idx >= count) return;
+        if (SINK == 0) { K.keys[idx] = ((u64)((u32)key & K.mask) << 32) | (key >> 32); K.pos[idx] = K.pos_base + (u32)idx; return; }
+        settle();
+        pend_bucket = (u32)key & K.mask;
+        pend_hash = (u32)(key >> 32);
+        pend_line = K.lines + pend_bucket * WORDS;
+        pend_slot = atomicAdd(pend_line, 1u);
+    };
     fe Sx, Sy;
     fe_load2(Sx, bases + (u64)tid * 4 + 0, bases + (u64)tid * 4 + 1);
     fe_load2(Sy, bases + (u64)tid * 4 + 2, bases + (u64)tid * 4 + 3);
-    if (tid < count) keys[tid] = ((u64)Sx.v[1] << 32) | Sx.v[0];
-    if (pi == 1) return;
+    emit(tid, ((u64)Sx.v[1] << 32) | Sx.v[0]);
+    if (pi == 1) { settle(); return; }
     fe nSx;
     fe_neg(nSx, Sx);
     fe acc;
@@ -38,22 +73,23 @@ __global__ void __launch_bounds__(256) baby_keys_kernel(const u32x4 *__restrict_
         fe_sub(d, hx, Sx);
         if (__builtin_expect(fe_eq(hx, Sx), 0)) fe_add(d, Sy, Sy);          // S + S: tangent
         fe_mul(acc, acc, d);
-        fe_store2(chain + ((u64)j * 2 + 0) * T + tid, chain + ((u64)j * 2 + 1) * T + tid, acc);
+        fe_store2_nt(chain + ((u64)j * 2 + 0) * T + tid, chain + ((u64)j * 2 + 1) * T + tid, acc);
     }
     fe inv;
     fe_inv(inv, acc);
+    fe c;                                                                    // the running product before point j, requested one point ahead
+    if (pi > 2) fe_load2_nt(c, chain + ((u64)(pi - 2) * 2 + 0) * T + tid, chain + ((u64)(pi - 2) * 2 + 1) * T + tid);
     for (u32 j = pi - 1; j >= 1; j--) {
-        fe hx, hy, d, s, t, lam, x, nhx;
+        fe hx, hy, d, s, t, lam, nhx;
         fe_load2(hx, helper + (u64)(j - 1) * 4 + 0, helper + (u64)(j - 1) * 4 + 1);
         fe_load2(hy, helper + (u64)(j - 1) * 4 + 2, helper + (u64)(j - 1) * 4 + 3);
         const bool dbl = fe_eq(hx, Sx);
         fe_sub(d, hx, Sx);
         if (__builtin_expect(dbl, 0)) fe_add(d, Sy, Sy);
         if (j > 1) {
-            fe c;
-            fe_load2(c, chain + ((u64)(j - 1) * 2 + 0) * T + tid, chain + ((u64)(j - 1) * 2 + 1) * T + tid);
             fe_mul(s, inv, c);
             fe_mul(inv, inv, d);
+            if (j > 2) fe_load2_nt(c, chain + ((u64)(j - 2) * 2 + 0) * T + tid, chain + ((u64)(j - 2) * 2 + 1) * T + tid);
         } else {
             s = inv;
         }
@@ -61,20 +97,11 @@ __global__ void __launch_bounds__(256) baby_keys_kernel(const u32x4 *__restrict_
         if (__builtin_expect(dbl, 0)) { fe x2; fe_sqr(x2, Sx); fe_add(t, x2, x2); fe_add(t, t, x2); }
         fe_mul(lam, t, s);
         fe_neg(nhx, hx);
-        x_from_lambda(x, lam, nSx, nhx);
-        const u64 idx = (u64)j * T + tid;
-        if (idx < count) keys[idx] = ((u64)x.v[1] << 32) | x.v[0];
+        fe_lo64_addends cad;
+        fe_lo64_prepare(cad, nSx, nhx);                                      // the probe reads 64 bits of x: so does the table (fp256.hip.h)
+        emit((u64)j * T + tid, x_key_from_lambda(lam, nSx, nhx, cad));
     }
-}
-
-// sort key = bucket << 32 | hash ; value = position (197:2561, 2583, 1221)
-__global__ void sortkeys_kernel(const u64 *__restrict__ keys, u64 *__restrict__ sk, u32 *__restrict__ pos, u64 n, u64 first_pos, u32 mask)
-{
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const u64 k = keys[i];
-        sk[i] = ((u64)((u32)k & mask) << 32) | (k >> 32);
-        pos[i] = (u32)(first_pos + i);
-    }
+    settle();
 }
 
 // bucket starts: off[b] = number of entries in buckets < b ; off[ht_items] = w
@@ -98,11 +125,78 @@ __global__ void csr_items_kernel(const u64 *__restrict__ sk, const u32 *__restri
 }
 
 namespace {
+// BSGS_BUILD_VERBOSE=1: stage times of the builders on stderr (wall clock; `sync` drains the stream first so that a stage owns its GPU time)
+struct StageClock {
+    bool on = getenv("BSGS_BUILD_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(bsgs_dev *d, const char *what, bool sync = true)
+    {
+        if (!on) return;
+        if (sync) (void)hipStreamSynchronize(d->stream);
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[build] %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) { return bsgs_big_malloc(&p, n ? n : 1); }      // parked scratch pieces are handed back on demand
     template <class T> T *as() { return (T *)p; }
+};
+
+// The point generator shared by both builders: k*G for k = first .. first + count - 1, `chunk` points per launch, nothing on the host in between
+// (round 3 computed every chunk's 65536 base points on the host, one synchronisation per chunk, and ran the kernel with one wave per SIMD).
+//   bases (first + tid)*G: walk_centres_kernel -- the device walk of the tile centres -- with D = G and P0 = first*G;
+//   helper j*(T*G), j = 1..pi-1: host EC library, once.
+struct KeyGen {
+    bsgs_dev *d = nullptr;
+    uint32_t T = 0, pi = 0;
+    uint64_t chunk = 0;
+    DevBuf chainb, helperb, basesb, gtab, status;
+    static void geometry(uint64_t w, uint32_t &T, uint32_t &pi)
+    {
+        pi = w >= (1ull << 26) ? 1024 : 256;                        // points per inversion (279 multiplications per block of four waves ... per thread here: 270)
+        uint64_t t = 256;
+        while (t < (1u << 18) && t * pi < w) t *= 2;                // 2^18 threads = four waves per SIMD on 256 CUs; fewer for small tables
+        T = (uint32_t)t;
+    }
+    static uint64_t scratch_bytes(uint64_t w) { uint32_t T, pi; geometry(w, T, pi); return (uint64_t)T * pi * 32 + (uint64_t)T * 64 + (1u << 20); }
+    int init(bsgs_dev *dev, uint64_t w)
+    {
+        d = dev;
+        geometry(w, T, pi);
+        chunk = (uint64_t)T * pi;
+        HIPCHK(chainb.alloc((uint64_t)T * pi * 32));
+        HIPCHK(basesb.alloc((size_t)T * 64));
+        HIPCHK(status.alloc(4));
+        HIPCHK(hipMemsetAsync(status.p, 0, 4, d->stream));
+        const hs::Affine TG = hs::point_mul(hs::G, hs::fe_from_u64(T));
+        std::vector<hs::Affine> helper = hs::multiples(TG, pi - 1);
+        std::vector<uint8_t> hb((size_t)(pi - 1) * 64), tab(64 * 64);
+        for (size_t i = 0; i + 1 < pi; i++) hs::affine_to_le(helper[i], &hb[i * 64], &hb[i * 64 + 32]);
+        hs::Affine cur = hs::G;
+        for (int j = 0; j < 64; j++) { hs::affine_to_le(cur, &tab[(size_t)j * 64], &tab[(size_t)j * 64 + 32]); cur = hs::point_add(cur, cur); }
+        HIPCHK(helperb.alloc(hb.size()));
+        HIPCHK(gtab.alloc(tab.size()));
+        HIPCHK(hipMemcpy(helperb.p, hb.data(), hb.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(gtab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
+        return BSGS_OK;
+    }
+    // queue the generation of points first .. first + count - 1 (count <= chunk) into the sink; asynchronous
+    template <int SINK>
+    int run(uint64_t first, uint64_t count, const KeySink &K)
+    {
+        const hs::Affine start = hs::point_mul(hs::G, hs::fe_from_u64(first));
+        fe p0x, p0y;
+        hs::affine_to_le(start, (uint8_t *)p0x.v, (uint8_t *)p0y.v);
+        hipLaunchKernelGGL(walk_centres_kernel, dim3((T + 63) / 64), dim3(64), 0, d->stream, p0x, p0y, gtab.as<const fe>(), (u64)0, (u32)T,
+                           basesb.as<fe>(), status.as<u32>());
+        hipLaunchKernelGGL(baby_keys_kernel<SINK>, dim3((T + 255) / 256), dim3(256), 0, d->stream, helperb.as<const u32x4>(), basesb.as<const u32x4>(), K,
+                           chainb.as<u32x4>(), T, pi, count);
+        HIPCHK(hipGetLastError());
+        return BSGS_OK;
+    }
 };
 }  // namespace
 
@@ -110,53 +204,32 @@ struct DevBuf {
 static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img, u32 *cpu_img)
 {
     const uint64_t ht_items = 1ull << htsz;
-    // geometry of one generation chunk: T threads x pi points
-    const uint32_t T = 1u << 16, pi = 512;
-    const uint64_t chunk = (uint64_t)T * pi;
-    DevBuf keys, sk, sk2, pos, pos2, chainb, helperb, basesb, tmp, offs;
-    HIPCHK(keys.alloc(w * 8));
-    HIPCHK(chainb.alloc((uint64_t)T * pi * 32));
-    // helper j*(T*G), j = 1..pi-1  (host EC library; a few hundred points)
-    const hs::Affine TG = hs::point_mul(hs::G, hs::fe_from_u64(T));
+    StageClock clk;
+    DevBuf sk, sk2, pos, pos2, tmp, offs;
+    HIPCHK(sk.alloc(w * 8)); HIPCHK(pos.alloc(w * 4));
     {
-        std::vector<hs::Affine> helper = hs::multiples(TG, pi - 1);
-        std::vector<uint8_t> hb((size_t)(pi - 1) * 64);
-        for (size_t i = 0; i + 1 < pi; i++) hs::affine_to_le(helper[i], &hb[i * 64], &hb[i * 64 + 32]);
-        HIPCHK(helperb.alloc(hb.size()));
-        HIPCHK(hipMemcpy(helperb.p, hb.data(), hb.size(), hipMemcpyHostToDevice));
-    }
-    HIPCHK(basesb.alloc((size_t)T * 64));
-    std::vector<uint8_t> bb((size_t)T * 64);
-    for (uint64_t first = 1; first <= w; first += chunk) {
-        const uint64_t count = std::min<uint64_t>(chunk, w - first + 1);
-        // bases (first + tid)*G for tid < T: consecutive multiples from a scalar-multiplied start
-        {
-            const hs::Affine start = hs::point_mul(hs::G, hs::fe_from_u64(first));
-            std::vector<hs::Jac> j(T);
-            hs::Jac cur = hs::to_jac(start);
-            for (uint32_t i = 0; i < T; i++) { j[i] = cur; cur = hs::jac_add_affine(cur, hs::G); }
-            std::vector<hs::Affine> a = hs::batch_to_affine(j);
-            for (uint32_t i = 0; i < T; i++) hs::affine_to_le(a[i], &bb[(size_t)i * 64], &bb[(size_t)i * 64 + 32]);
+        KeyGen gen;
+        int rc = gen.init(d, w);
+        if (rc) return rc;
+        KeySink K{};
+        K.mask = (u32)(ht_items - 1);
+        for (uint64_t first = 1; first <= w; first += gen.chunk) {
+            K.keys = sk.as<u64>() + (first - 1); K.pos = pos.as<u32>() + (first - 1); K.pos_base = (u32)(first - 1);
+            rc = gen.run<0>(first, std::min<uint64_t>(gen.chunk, w - first + 1), K);
+            if (rc) return rc;
         }
-        HIPCHK(hipMemcpyAsync(basesb.p, bb.data(), bb.size(), hipMemcpyHostToDevice, d->stream));
-        hipLaunchKernelGGL(baby_keys_kernel, dim3(T / 256), dim3(256), 0, d->stream, helperb.as<const u32x4>(), basesb.as<const u32x4>(),
-                           keys.as<u64>() + (first - 1), chainb.as<u32x4>(), T, pi, count);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(d->stream));      // bb is reused by the next chunk
+        HIPCHK(hipStreamSynchronize(d->stream));                 // the generator's scratch goes out of scope here
+        clk.lap(d, "generate the points (keys)");
     }
-    (void)hipFree(chainb.p); chainb.p = nullptr;
-    // sort by (bucket, hash), positions ride along
-    HIPCHK(sk.alloc(w * 8)); HIPCHK(sk2.alloc(w * 8)); HIPCHK(pos.alloc(w * 4)); HIPCHK(pos2.alloc(w * 4));
+    // sort by (bucket, hash), positions ride along (stable: entries with an identical (bucket, hash) pair stay in ascending position order)
+    HIPCHK(sk2.alloc(w * 8)); HIPCHK(pos2.alloc(w * 4));
     const int gblocks = (int)std::min<uint64_t>((w + 255) / 256, 1u << 16);
-    hipLaunchKernelGGL(sortkeys_kernel, dim3(gblocks), dim3(256), 0, d->stream, keys.as<const u64>(), sk.as<u64>(), pos.as<u32>(), w, 0ull,
-                       (u32)(ht_items - 1));
-    HIPCHK(hipGetLastError());
     size_t tmp_bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, sk.as<u64>(), sk2.as<u64>(), pos.as<u32>(), pos2.as<u32>(), (size_t)w, 0u, 32u + htsz, d->stream));
     HIPCHK(tmp.alloc(tmp_bytes));
     HIPCHK(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, sk.as<u64>(), sk2.as<u64>(), pos.as<u32>(), pos2.as<u32>(), (size_t)w, 0u, 32u + htsz, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    (void)hipFree(keys.p); keys.p = nullptr;
+    clk.lap(d, "radix sort by (bucket, hash)");
     (void)hipFree(sk.p); sk.p = nullptr;
     (void)hipFree(pos.p); pos.p = nullptr;
     // images
@@ -169,6 +242,7 @@ static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img,
     HIPCHK(hipGetLastError());
     if (gpu_img && cpu_img) HIPCHK(hipMemcpyAsync(cpu_img, gpu_img, hdr, hipMemcpyDeviceToDevice, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
+    clk.lap(d, "bucket starts + file images");
     return BSGS_OK;
 }
 
@@ -217,59 +291,39 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
     HIPCHK(listb.alloc(ovf_cap * 8));
     u64 *ovf = listb.as<u64>();
     const uint64_t ht_items = 1ull << htsz, line_bytes = 64ull << (lplog - 2);
-    // one generation chunk = T threads x pi points; large chunks keep the host-side base points (T per chunk) off the clock
-    const uint32_t T = 1u << 16, pi = w > (1ull << 28) ? 4096 : 512;
-    const uint64_t chunk = (uint64_t)T * pi;
+    StageClock clk;
     size_t fr = 0, tot = 0;
     HIPCHK(bsgs_mem_available(&fr, &tot));
-    const uint64_t need = std::min(chunk, w) * 8 + (uint64_t)T * pi * 32 + (64ull << 20);     // keys, chain
+    const uint64_t need = KeyGen::scratch_bytes(w) + (64ull << 20);
     if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table build needs %.1f GiB of scratch, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
-    DevBuf keys, chainb, helperb, basesb, cnt;
+    DevBuf cnt;
     HIPCHK(hipMemsetAsync(lines, 0, ht_items * line_bytes, d->stream));
     HIPCHK(cnt.alloc(16));
     HIPCHK(hipMemsetAsync(cnt.p, 0, 16, d->stream));
-    HIPCHK(keys.alloc(std::min(chunk, w) * 8));
-    HIPCHK(chainb.alloc((uint64_t)T * pi * 32));
-    const hs::Affine TG = hs::point_mul(hs::G, hs::fe_from_u64(T));
+    clk.lap(d, "clear the bucket lines");
     {
-        std::vector<hs::Affine> helper = hs::multiples(TG, pi - 1);
-        std::vector<uint8_t> hb((size_t)(pi - 1) * 64);
-        for (size_t i = 0; i + 1 < pi; i++) hs::affine_to_le(helper[i], &hb[i * 64], &hb[i * 64 + 32]);
-        HIPCHK(helperb.alloc(hb.size()));
-        HIPCHK(hipMemcpy(helperb.p, hb.data(), hb.size(), hipMemcpyHostToDevice));
-    }
-    HIPCHK(basesb.alloc((size_t)T * 64));
-    std::vector<uint8_t> bb((size_t)T * 64);
-    const u32 mask = (u32)(ht_items - 1);
-    for (uint64_t first = 1; first <= w; first += chunk) {
-        const uint64_t count = std::min<uint64_t>(chunk, w - first + 1);
-        {
-            const hs::Affine start = hs::point_mul(hs::G, hs::fe_from_u64(first));
-            std::vector<hs::Jac> j(T);
-            hs::Jac cur = hs::to_jac(start);
-            for (uint32_t i = 0; i < T; i++) { j[i] = cur; cur = hs::jac_add_affine(cur, hs::G); }
-            std::vector<hs::Affine> a = hs::batch_to_affine(j);
-            HIPCHK(hipStreamSynchronize(d->stream));                 // bb is still the source of the previous chunk's copy
-            for (uint32_t i = 0; i < T; i++) hs::affine_to_le(a[i], &bb[(size_t)i * 64], &bb[(size_t)i * 64 + 32]);
+        KeyGen gen;
+        int rc = gen.init(d, w);
+        if (rc) return rc;
+        KeySink K{};
+        K.lines = (u32 *)lines; K.ovf = ovf; K.ovf_cap = ovf_cap; K.counters = cnt.as<unsigned long long>(); K.mask = (u32)(ht_items - 1);
+        for (uint64_t first = 1; first <= w && rc == BSGS_OK; first += gen.chunk) {
+            const uint64_t count = std::min<uint64_t>(gen.chunk, w - first + 1);
+            rc = lplog == 2 ? gen.run<2>(first, count, K) : gen.run<3>(first, count, K);
         }
-        HIPCHK(hipMemcpyAsync(basesb.p, bb.data(), bb.size(), hipMemcpyHostToDevice, d->stream));
-        hipLaunchKernelGGL(baby_keys_kernel, dim3(T / 256), dim3(256), 0, d->stream, helperb.as<const u32x4>(), basesb.as<const u32x4>(),
-                           keys.as<u64>(), chainb.as<u32x4>(), T, pi, count);
-        const int sblocks = (int)std::min<uint64_t>((count + 255) / 256, 1u << 16);
-        if (lplog == 2) hipLaunchKernelGGL(ext_scatter_kernel<2>, dim3(sblocks), dim3(256), 0, d->stream, keys.as<const u64>(), count, mask, (u32 *)lines, ovf, ovf_cap, cnt.as<unsigned long long>());
-        else            hipLaunchKernelGGL(ext_scatter_kernel<3>, dim3(sblocks), dim3(256), 0, d->stream, keys.as<const u64>(), count, mask, (u32 *)lines, ovf, ovf_cap, cnt.as<unsigned long long>());
-        HIPCHK(hipGetLastError());
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(d->stream));                 // the generator's scratch goes out of scope here
+        clk.lap(d, "generate + scatter the points");
     }
-    const int fblocks = (int)std::min<uint64_t>((ht_items + 255) / 256, 1u << 20);
-    if (lplog == 2) hipLaunchKernelGGL(ext_finalize_kernel<2>, dim3(fblocks), dim3(256), 0, d->stream, (u32 *)lines, ht_items, cnt.as<unsigned long long>());
-    else            hipLaunchKernelGGL(ext_finalize_kernel<3>, dim3(fblocks), dim3(256), 0, d->stream, (u32 *)lines, ht_items, cnt.as<unsigned long long>());
+    const int fblocks = (int)std::min<uint64_t>(((ht_items << lplog) + 255) / 256, (uint64_t)d->prop.multiProcessorCount * 32);
+    if (lplog == 2) hipLaunchKernelGGL(ext_finalize_kernel<2>, dim3(fblocks), dim3(256), 0, d->stream, lines, ht_items, cnt.as<unsigned long long>());
+    else            hipLaunchKernelGGL(ext_finalize_kernel<3>, dim3(fblocks), dim3(256), 0, d->stream, lines, ht_items, cnt.as<unsigned long long>());
     HIPCHK(hipGetLastError());
     unsigned long long h[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     if (h[1] > ovf_cap) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries, capacity %llu", h[1], (unsigned long long)ovf_cap);
-    (void)hipFree(chainb.p); chainb.p = nullptr;
-    (void)hipFree(keys.p); keys.p = nullptr;
+    clk.lap(d, "close the lines (pad, count)");
     if (h[1]) {
         // OVERFLOW BOUND (giant_kernel.hip.h): sort the overflow list by (bucket, hash), then per bucket keep the smallest hashes in the line
         // and put the smallest of the others into the line's last word
@@ -288,6 +342,7 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
     }
     int rc = bsgs_ovf_fill(d, ovf, h[1], ovf_table, ovf_slots);
     if (rc) return rc;
+    clk.lap(d, "overflow list: sort, refine, set");
     *ovf_n = ovf_slots; *overflow_buckets = h[0];
     return BSGS_OK;
 }
@@ -364,7 +419,9 @@ extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz,
     if (ht_items * line_bytes + ovf_cap * 8 > fr) return fail(BSGS_ERR_NOMEM, "extended table needs %.1f GiB, %.1f GiB free", (ht_items * line_bytes + ovf_cap * 8) / 1073741824.0, fr / 1073741824.0);
     u32x4 *lines = nullptr;
     u64 *ovf = nullptr;
+    StageClock clk;
     HIPCHK(bsgs_lines_malloc(d, (void **)&lines, ht_items * line_bytes));
+    clk.lap(d, "allocate the bucket lines (placed)");
     hipError_t e = bsgs_big_malloc((void **)&ovf, ovf_cap * 8);
     if (e != hipSuccess) { (void)hipFree(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
     uint64_t n = 0, ob = 0;

@@ -422,8 +422,72 @@ static int dpf_check()
     return bad;
 }
 
+// ---------------------------------------------------------------- scatter into bucket lines (round 4: what bounds the baby-table builder)
+// Every key claims a slot of a random 64-byte line with an atomic add on the line's word 0 and stores its hash into the slot it got (the
+// dependent store of ext_scatter_kernel).  MODE 0: device-scope atomic (what hipcc emits for atomicAdd); 1: workgroup-scope atomic, and every
+// block only touches the lines of ITS XCD (line index mod 8 == XCC_ID: the atomics then execute in that XCD's L2 and no other XCD ever sees
+// the line during the kernel); 2: no atomic at all, a plain load of word 0 and two stores (wrong counts; the memory system's own ceiling for
+// a random read-modify-write of a line); 3: MODE 1's atomics without the XCD discipline (wrong in general; isolates the cost of the scope)
+template <int MODE>
+__global__ void __launch_bounds__(256) scatter_kernel(u32 *__restrict__ lines, u64 line_mask, int iters, u64 seed)
+{
+    const u32 tid = threadIdx.x + blockIdx.x * blockDim.x;
+    u64 s = seed + (u64)tid * 0x632BE59BD9B4E019ULL;
+    const u32 xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;             // HW_REG_XCC_ID[3:0]
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s += 0x9E3779B97F4A7C15ULL;
+            u64 z = s;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            u64 line = z & line_mask;
+            if (MODE == 1) line = (line & ~7ull) | xcc;
+            u32 *L = lines + line * 16;
+            u32 slot;
+            if (MODE == 0) slot = atomicAdd(L, 1u);
+            else if (MODE == 1 || MODE == 3) slot = __hip_atomic_fetch_add(L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else { slot = L[0]; L[0] = slot + 1; }
+            L[1 + (slot % 15u)] = (u32)(z >> 32);
+        }
+    }
+}
+template <int MODE>
+static void run_scatter(const char *name, u32 *lines, size_t bytes)
+{
+    const u64 nlines = bytes / 64;
+    u64 mask = 1; while (mask * 2 <= nlines) mask *= 2; mask -= 1;
+    const int blocks = 256 * 16, iters = 64;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipMemsetAsync(lines, 0, bytes));
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(scatter_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, lines, mask, iters, 1234567ull + rep);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    const double keys = (double)blocks * 256 * iters * 4;
+    printf("{\"bench\":\"scatter\",\"mode\":\"%s\",\"footprint_GiB\":%.1f,\"Gkeys_per_s\":%.2f,\"ms\":%.2f}\n", name, bytes / 1073741824.0, keys / (best * 1e-3) / 1e9, best);
+    fflush(stdout);
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && !strcmp(argv[1], "scatter")) {
+        for (int i = 2; i < argc; i++) {
+            const size_t bytes = (size_t)atoll(argv[i]) << 20;
+            u32 *lines; CK(hipMalloc(&lines, bytes));
+            run_scatter<0>("device-scope atomicAdd + dependent store", lines, bytes);
+            run_scatter<1>("workgroup-scope atomic, lines partitioned by XCD + dependent store", lines, bytes);
+            run_scatter<3>("workgroup-scope atomic, NOT partitioned (wrong in general)", lines, bytes);
+            run_scatter<2>("plain load + two stores (no atomic: wrong counts)", lines, bytes);
+            CK(hipFree(lines));
+        }
+        return 0;
+    }
     if (argc >= 2 && !strcmp(argv[1], "dpfcheck")) return dpf_check() ? 1 : 0;
     if (argc >= 4 && !strcmp(argv[1], "power")) {
         u32 *dout; CK(hipMalloc(&dout, 256 * 8 * 256 * 4));

@@ -263,21 +263,37 @@ hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
         struct P { void *p; float g; };
         std::vector<P> all;
         float top = 0.f;
+        const bool verbose = getenv("BSGS_BUILD_VERBOSE") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+        auto t_walk = now();
+        double ms_malloc = 0, ms_grade = 0;
         for (;;) {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece + (2ull << 30)) break;
             void *p = nullptr;
+            auto t0 = now();
             if (hipMalloc(&p, piece) != hipSuccess) { (void)hipGetLastError(); break; }
+            ms_malloc += ms_since(t0); t0 = now();
             const float g = G.grade(p, piece);
+            ms_grade += ms_since(t0);
             top = std::max(top, g);
             all.push_back({p, g});
         }
         (void)hipStreamSynchronize(d->stream);
+        if (verbose) {
+            fprintf(stderr, "[place] walk: %zu pieces of 4 GiB in %.0f ms (hipMalloc %.0f ms, grading %.0f ms); grades in allocation order:", all.size(), ms_since(t_walk), ms_malloc, ms_grade);
+            for (const P &x : all) fprintf(stderr, " %.1f", x.g);
+            fprintf(stderr, "\n");
+        }
+        auto t_free = now();
         float lo = 1e30f, hi = 0.f;
         for (const P &x : all) {
             if (x.g <= 0.93f * top && d->group0_reserve.size() < 24) { d->group0_reserve.push_back(x.p); lo = std::min(lo, x.g); hi = std::max(hi, x.g); }
             else (void)hipFree(x.p);
         }
+        if (verbose) fprintf(stderr, "[place] %zu pieces held back, %zu handed back in %.0f ms\n", d->group0_reserve.size(), all.size() - d->group0_reserve.size(), ms_since(t_free));
+        auto t_big = now();
         d->group0_piece_bytes = piece; d->group0_graded = (uint32_t)all.size(); d->group0_grade_lo = lo > 1e29f ? 0.f : lo; d->group0_grade_hi = hi;
         if (getenv("BSGS_TUNE_VERBOSE")) fprintf(stderr, "[lines] %.1f GiB: %zu pieces graded (top %.1f), %zu of group 0 held back for the chain scratch (%.1f...%.1f)\n",
                                                  bytes / 1073741824.0, all.size(), top, d->group0_reserve.size(), d->group0_grade_lo, hi);
@@ -292,6 +308,7 @@ hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
         };
         hipError_t e = patient(32);
         if (e != hipSuccess) { free_reserve(d); e = patient(32); }         // not with the reserve in the way: without it
+        if (verbose) fprintf(stderr, "[place] hipMalloc of the %.0f GiB of lines: %.0f ms\n", bytes / 1073741824.0, ms_since(t_big));
         return e;
     }
 }
