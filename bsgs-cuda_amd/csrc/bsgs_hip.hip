@@ -720,6 +720,9 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = pi; A.T = Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;
+#ifdef BSGS_G2_CACHED_CEILING
+    A.pad0 = 1;                          // experiment build only (results WRONG): every giant read hits one cached KiB per wave
+#endif
     A.centres_dev = centres_dev;
     A.digest = d->digest ? d->digest + (uint64_t)seq * Ti * 2 : nullptr;
     A.chain_pad = d->chain_pad; A.chain_mode = 0;
@@ -1461,6 +1464,73 @@ extern "C" int bsgs_bench_random_read(bsgs_dev *d, uint64_t footprint_bytes, uin
     if (gbps) *gbps = reads * granule / (ms * 1e-3) / 1e9;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(buf); (void)hipFree(out);
+    return BSGS_OK;
+}
+
+// ---- counter calibration streams -----------------------------------------------------------------------------------------------
+// rocprofv3's FETCH_SIZE / WRITE_SIZE are request counters with a nominal size; what they report per byte depends on the access pattern
+// (MI355X_MICROARCH.md, HBM: wide coalesced 16-byte-per-lane reads are tallied at 1/2).  The tile kernel mixes three patterns -- random
+// 4 x 16-byte line reads by LDS-DMA (the probes), coalesced 16-byte-per-lane reads by plain loads and by LDS-DMA (giants, stored products),
+// coalesced non-temporal 16-byte stores (stored products) -- so bench.py's counter passes run each pattern ONCE over a known number of bytes
+// in the same process and divide: kind 0 = plain coalesced reads, 1 = coalesced reads by global_load_lds_dwordx4, 2 = non-temporal stores;
+// bsgs_bench_random_read is the probe pattern.  Every kernel touches each of the `bytes` exactly once.
+static __global__ void __launch_bounds__(256) mb_stream_read_kernel(const u32x4 *__restrict__ buf, u64 n16, u32 *out)
+{
+    u32 acc = 0;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x) {
+        const u32x4 v = buf[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9abcdef1u) out[0] = acc;
+}
+static __global__ void __launch_bounds__(256) mb_stream_read_lds_kernel(const u32x4 *__restrict__ buf, u64 n16, u32 *out)
+{
+    __shared__ __attribute__((aligned(16))) char slot[4096];                     // 1 KiB per wave: where the DMA lands
+    const u32 wave_base = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
+    u32 acc = 0;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < ((n16 + 63) & ~63ull); i += (u64)gridDim.x * blockDim.x) {
+        if (i < n16) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(buf + i),
+                                                      (__attribute__((address_space(3))) void *)(slot + wave_base), 16, 0, 2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc ^= *(const u32 *)(slot + wave_base + (threadIdx.x & 63) * 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (acc == 0x9abcdef1u) out[0] = acc;
+}
+static __global__ void __launch_bounds__(256) mb_stream_write_nt_kernel(u32x4 *__restrict__ buf, u64 n16, u32 seed)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x) {
+        const u32x4 v = {seed, (u32)i, (u32)(i >> 32), seed ^ (u32)i};
+        __builtin_nontemporal_store(v, buf + i);
+    }
+}
+extern "C" int bsgs_bench_stream(bsgs_dev *d, int kind, uint64_t bytes, double *gbps)
+{
+    if (!d || kind < 0 || kind > 2 || bytes < (1ull << 20)) return fail(BSGS_ERR_ARG, "kind 0..2, at least 1 MiB");
+    HIPCHK(hipSetDevice(d->id));
+    void *buf = nullptr; u32 *out = nullptr;
+    HIPCHK(bsgs_big_malloc(&buf, bytes));
+    if (hipMalloc(&out, 64) != hipSuccess) { (void)hipFree(buf); return fail(BSGS_ERR_NOMEM, "out word"); }
+    hipError_t e = hipMemsetAsync(buf, 0x5a, bytes, d->stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const u64 n16 = bytes / 16;
+    const int blocks = d->prop.multiProcessorCount * 16;
+    if (e == hipSuccess) e = hipEventRecord(e0, d->stream);
+    if (kind == 0) hipLaunchKernelGGL(mb_stream_read_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)buf, n16, out);
+    else if (kind == 1) hipLaunchKernelGGL(mb_stream_read_lds_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)buf, n16, out);
+    else hipLaunchKernelGGL(mb_stream_write_nt_kernel, dim3(blocks), dim3(256), 0, d->stream, (u32x4 *)buf, n16, 7u);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(e1, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf); (void)hipFree(out);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "bench_stream: %s", hipGetErrorString(e));
+    if (gbps) *gbps = ms > 0.f ? bytes / (ms * 1e-3) / 1e9 : 0.0;
     return BSGS_OK;
 }
 

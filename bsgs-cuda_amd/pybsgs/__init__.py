@@ -22,7 +22,7 @@ NATIVE_SYMBOLS = [
     "bsgs_dev_meminfo", "bsgs_dev_cu_count", "bsgs_upload_g2", "bsgs_upload_g2_device", "bsgs_generate_g2",
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
-    "bsgs_bench_random_read", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
+    "bsgs_bench_random_read", "bsgs_bench_stream", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
     "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_debug_xcd_profile",
     "bsgs_table_checksum", "bsgs_debug_corrupt_table", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
@@ -110,6 +110,7 @@ def lib():
             "bsgs_selftest_xs": [vp, u8p, u8p, C.c_uint64, C.c_uint32, vp],
             "bsgs_bench_random_read": [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)],
             "bsgs_bench_modmul": [vp, C.POINTER(C.c_double)],
+            "bsgs_bench_stream": [vp, C.c_int, C.c_uint64, C.POINTER(C.c_double)],
             "bsgs_set_tiles_per_launch": [vp, C.c_uint32],
             "bsgs_launch_count": [vp, C.POINTER(C.c_uint64)],
             "bsgs_build_baby_tables": [vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32],
@@ -427,6 +428,12 @@ class Device:
         g, r = C.c_double(), C.c_double()
         _chk(self.L.bsgs_bench_random_read(self.h, footprint_bytes, granule, C.byref(g), C.byref(r)))
         return g.value, r.value
+
+    def bench_stream(self, kind, nbytes):
+        """GB/s of one pass over nbytes in a streaming pattern of the tile kernel (0 coalesced loads, 1 the same by LDS-DMA, 2 non-temporal stores)"""
+        g = C.c_double()
+        _chk(self.L.bsgs_bench_stream(self.h, kind, nbytes, C.byref(g)))
+        return g.value
 
     def debug_buffers(self, measure=True):
         a = (C.c_uint64 * 5)()
