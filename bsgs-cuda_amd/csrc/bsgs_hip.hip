@@ -785,6 +785,19 @@ static int quirk_prepare(bsgs_dev *d)
     return BSGS_OK;
 }
 
+// how many giants of the resident G2 trip the reference's NEGMODP (the list reference-quirk mode re-computes after every launch)
+extern "C" int bsgs_quirk_count(bsgs_dev *d, uint32_t *listed)
+{
+    if (!d || !listed) return fail(BSGS_ERR_ARG, "null");
+    if (!d->g2) return fail(BSGS_ERR_STATE, "no giants on device");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    HIPCHK(hipSetDevice(d->id));
+    int rc = quirk_prepare(d);
+    if (rc) return rc;
+    *listed = (uint32_t)d->quirk_host.size();
+    return BSGS_OK;
+}
+
 // queue `ntiles` tiles whose centres are already in d->cen_dev[2*queued ...]
 static int enqueue_common(bsgs_dev *d, uint32_t ntiles)
 {
@@ -890,6 +903,16 @@ extern "C" int bsgs_chain_placement(bsgs_dev *d, uint32_t info[5], float grade[2
     info[0] = (uint32_t)d->chain_pieces.size(); info[1] = d->chain_pieces.empty() ? 0 : 1u << d->chain_piece_log;
     info[2] = d->chain_graded; info[3] = d->chain_rejected; info[4] = d->chain_from_reserve;
     grade[0] = d->chain_grade_best; grade[1] = d->chain_grade_worst;
+    return BSGS_OK;
+}
+
+// every grade the last graded allocation of the chain scratch saw (G gathers/s), the kept pieces first; *separated = 1 when two classes were seen
+extern "C" int bsgs_chain_grades(bsgs_dev *d, float *grades, uint32_t cap, uint32_t *n, uint32_t *separated)
+{
+    if (!d || !n) return fail(BSGS_ERR_ARG, "null");
+    *n = (uint32_t)d->chain_grades.size();
+    if (separated) *separated = d->chain_separated;
+    for (uint32_t k = 0; grades && k < cap && k < *n; k++) grades[k] = d->chain_grades[k];
     return BSGS_OK;
 }
 

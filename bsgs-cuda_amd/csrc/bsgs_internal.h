@@ -37,6 +37,8 @@ struct bsgs_dev {
     unsigned long long *grade_idx = nullptr, *grade_out = nullptr;   // the grader's index / output streams (kept for the engine's life: grades are relative to them)
     hipEvent_t grade_ea = nullptr, grade_eb = nullptr;
     uint32_t chain_from_reserve = 0;
+    uint32_t chain_separated = 0;                       // the last graded allocation saw two classes (a piece >= 5 % below the best); 0 = the grades carried no information
+    std::vector<float> chain_grades;                    // every grade of the last graded allocation, kept pieces first
     float chain_grade_best = 0.f, chain_grade_worst = 0.f;   // grade (G gathers/s) of the best / worst piece kept
     uint32_t chain_pad = 0;                       // extra u32x4 elements between the scratch areas of consecutive tiles
     std::vector<void *> pending_dev, pending_pinned;   // per-enqueue centre buffers, released by bsgs_collect

@@ -186,6 +186,48 @@ void free_chain_pieces(bsgs_dev *d)
     d->chain_pieces.clear();
     d->chain_piece_bytes = 0;
 }
+// ---- the grader's decision rule, free of any device (tests/test_abi.py drives it through bsgs_debug_grade_rule) ------------------------------
+// Pieces are drawn one at a time and graded (G gathers/s against the installed bucket lines: a piece that shares a memory group with them grades
+// 6-10 % lower, a straddler 2-3 %).  The rule says when to STOP drawing and WHICH pieces to keep; it makes no assumption about how many memory
+// groups a GPU shows (three on the MI355X boxes seen so far; another partition mode may show one class or five):
+//   stop    once `need` pieces are within 2 % of the best grade seen AND a separation was seen (some piece >= 5 % below the best: the best is then
+//           a far class) -- or `need + 12` pieces were looked at without one (one class is all there is) -- or `need + extra_max` in any case;
+//   keep    the `need` best (ties: the earlier allocation);
+//   verdict separated = a piece >= 5 % below the best was seen.  Without separation the grades carry no information: the first `need` pieces in
+//           allocation order are kept -- exactly what plain allocation would have given -- and the engine says so (chain_placement: separated 0).
+struct GradeRule {
+    static size_t good(const float *g, size_t n) { float best = 0.f; for (size_t k = 0; k < n; k++) best = std::max(best, g[k]); size_t c = 0; for (size_t k = 0; k < n; k++) c += g[k] >= 0.98f * best; return c; }
+    static bool separated(const float *g, size_t n) { float best = 0.f; for (size_t k = 0; k < n; k++) best = std::max(best, g[k]); for (size_t k = 0; k < n; k++) if (g[k] <= 0.95f * best) return true; return false; }
+    static bool stop(const float *g, size_t n, size_t need, size_t extra_max)
+    {
+        if (n < need) return false;
+        if (n >= need + extra_max) return true;
+        return good(g, n) >= need && (separated(g, n) || n >= need + 12);
+    }
+    // indices of the pieces to keep, best first
+    static std::vector<size_t> keep(const float *g, size_t n, size_t need)
+    {
+        std::vector<size_t> idx(n);
+        for (size_t k = 0; k < n; k++) idx[k] = k;
+        if (separated(g, n)) std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return g[a] > g[b]; });
+        idx.resize(std::min(need, n));
+        return idx;
+    }
+};
+// grades[0..n) = the grades in the order the pieces would be drawn; returns how many the rule draws, which it keeps, and whether it saw a separation
+extern "C" int bsgs_debug_grade_rule(const float *grades, uint32_t n, uint32_t need, uint32_t extra_max, uint32_t *drawn, uint32_t *kept, uint32_t *separated)
+{
+    if (!grades || !drawn || !kept || !separated || !need) return bsgs_fail(BSGS_ERR_ARG, "null");
+    uint32_t k = 0;
+    while (k < n && !GradeRule::stop(grades, k, need, extra_max)) k++;
+    *drawn = k;
+    const std::vector<size_t> idx = GradeRule::keep(grades, k, need);
+    for (size_t i = 0; i < idx.size(); i++) kept[i] = (uint32_t)idx[i];
+    for (size_t i = idx.size(); i < need; i++) kept[i] = 0xFFFFFFFFu;
+    *separated = GradeRule::separated(grades, k) ? 1u : 0u;
+    return BSGS_OK;
+}
+
 // npieces buffers of piece_bytes each, preferring the gather-fast class; false = not enough memory (nothing is left allocated)
 bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
 {
@@ -197,7 +239,7 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
         free_reserve(d);                                          // what the scratch does not need goes back to the driver
         d->chain_graded = d->group0_graded; d->chain_rejected = d->group0_graded - (uint32_t)npieces;
         d->chain_grade_best = d->group0_grade_lo; d->chain_grade_worst = d->group0_grade_hi;
-        d->chain_from_reserve = 1;
+        d->chain_from_reserve = 1; d->chain_separated = 1; d->chain_grades.clear();
         return true;
     }
     free_reserve(d);
@@ -208,26 +250,39 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
     const bool direct = d->lines && d->lines_bytes >= (1ull << 30) && piece_bytes >= (512ull << 20);     // grade against the installed bucket lines
     const bool can_grade = direct || G.init();
     const size_t extra = can_grade ? 24 + (getenv("BSGS_GRADE_MORE") ? 24 : 0) : 0;                  // at most this many more than needed (the slow class holds 16...22 granules of 4 GiB)
-    float best = 0.f;
-    auto good = [&]() { size_t n = 0; for (const Cand &c : cands) n += c.g >= 0.98f * best; return n; };      // pieces sharing a group with the lines grade 6-10 % lower, straddlers 2-3 %
-    // "enough pieces within 2 % of the best seen" only means something once BOTH classes were seen: consecutive allocations tend to come from one
+    // "enough pieces within 2 % of the best seen" only means something once a separation was seen: consecutive allocations tend to come from one
     // memory group, and with the 6 pieces a launch needs since round 3 (8 bytes per giant) the first six were sometimes all in the bucket lines'
-    // group -- uniformly bad, all "within 2 % of the best", 175 ms per launch instead of 160 (profiles/r04f_*).  So the draw goes on until some piece
-    // grades at least 5 % below the best (the best is then the far class), or 12 more than needed have been looked at (one class is all there is).
-    auto two_classes = [&]() { for (const Cand &c : cands) if (c.g <= 0.95f * best) return true; return false; };
+    // group -- uniformly bad, all "within 2 % of the best", 175 ms per launch instead of 160 (profiles/r04f_*): GradeRule above.
+    std::vector<float> grades;
     while (cands.size() < npieces + extra) {
         static const size_t grade_more = getenv("BSGS_GRADE_MORE") ? (size_t)atoi(getenv("BSGS_GRADE_MORE")) : 0;     // diagnostics: look at this many extra pieces
-        if (cands.size() >= npieces + grade_more && (!can_grade || (good() >= npieces && (two_classes() || cands.size() >= npieces + 12)))) break;
+        if (cands.size() >= npieces + grade_more && (!can_grade || GradeRule::stop(grades.data(), grades.size(), npieces, extra))) break;
         size_t fr = 0, tot = 0;
         if (cands.size() >= npieces && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < piece_bytes + (6ull << 30))) break;   // leave room for the rest of the engine
         void *p = nullptr;
         if ((cands.size() < npieces ? malloc_or_unpark(&p, piece_bytes) : hipMalloc(&p, piece_bytes)) != hipSuccess) { (void)hipGetLastError(); break; }
         const float g = !can_grade ? 1.f : direct ? G.grade_against(d->lines, d->lines_bytes, p) : G.grade(p, piece_bytes);
-        best = std::max(best, g);
         cands.push_back({p, g});
+        grades.push_back(g);
     }
     if (cands.size() < npieces) { for (const Cand &c : cands) (void)hipFree(c.p); return false; }
-    std::stable_sort(cands.begin(), cands.end(), [](const Cand &x, const Cand &y) { return x.g > y.g; });
+    // keep by the rule: the best `npieces` when a separation was seen, the first `npieces` drawn (= plain allocation) when the grades say nothing
+    const bool sep = can_grade && GradeRule::separated(grades.data(), grades.size());
+    {
+        const std::vector<size_t> kept = GradeRule::keep(grades.data(), grades.size(), npieces);
+        std::vector<Cand> ordered;
+        std::vector<bool> taken(cands.size(), false);
+        for (size_t k : kept) { ordered.push_back(cands[k]); taken[k] = true; }
+        for (size_t k = 0; k < cands.size(); k++) if (!taken[k]) ordered.push_back(cands[k]);
+        cands.swap(ordered);
+    }
+    d->chain_separated = sep ? 1 : 0;
+    d->chain_grades.clear();
+    for (const Cand &c : cands) d->chain_grades.push_back(c.g);          // kept pieces first
+    if (can_grade && !sep && cands.size() > npieces)
+        fprintf(stderr, "bsgs: chain scratch: %zu pieces graded %.1f ... %.1f G gathers/s, no separation of 5 %% between them -- this GPU shows one memory class here; "
+                        "the scratch is placed as plain allocation would (expect the launch time to vary with placement)\n", cands.size(),
+                *std::min_element(grades.begin(), grades.end()), *std::max_element(grades.begin(), grades.end()));
     (void)hipStreamSynchronize(d->stream);
     d->chain_pieces.clear();
     for (size_t k = 0; k < npieces; k++) d->chain_pieces.push_back((u32x4 *)cands[k].p);
@@ -238,7 +293,8 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
         for (size_t k = npieces; k < cands.size(); k++) { if (plenty) park(d->id, cands[k].p, piece_bytes); else (void)hipFree(cands[k].p); }
     }
     d->chain_graded = (uint32_t)cands.size(); d->chain_rejected = (uint32_t)(cands.size() - npieces);
-    d->chain_grade_best = cands[0].g; d->chain_grade_worst = cands[npieces - 1].g;
+    d->chain_grade_best = d->chain_grade_worst = cands[0].g;
+    for (size_t k = 0; k < npieces; k++) { d->chain_grade_best = std::max(d->chain_grade_best, cands[k].g); d->chain_grade_worst = std::min(d->chain_grade_worst, cands[k].g); }
     if (getenv("BSGS_TUNE_VERBOSE")) {
         fprintf(stderr, "[chain pieces] %zu x %.2f GiB, graded %zu:", npieces, piece_bytes / 1073741824.0, cands.size());
         for (size_t k = 0; k < cands.size(); k++) fprintf(stderr, "%s%.1f", k == npieces ? " | rejected " : " ", cands[k].g);

@@ -691,6 +691,13 @@ int main(int argc, char **argv)
     Shared S;
     S.cfg = parse_args(argc, argv);
     const Config &c = S.cfg;
+    // "[startup] <stage> <seconds>" lines: where the time before the first tile goes (bench.py's cold_time_to_solve_s reads them)
+    auto t_stage = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        const auto n = std::chrono::steady_clock::now();
+        printf("[startup] %-44s %.3fs\n", what, std::chrono::duration<double>(n - t_stage).count());
+        t_stage = n;
+    };
     int ngpu = 0;
     CK(bsgs_dev_count(&ngpu));
     if (ngpu <= 0) die("No GPU found");
@@ -698,7 +705,9 @@ int main(int argc, char **argv)
     if (c.devices.empty()) for (int i = 0; i < ngpu; i++) gpus.push_back(i);
     else { std::stringstream ss(c.devices); std::string tok; while (std::getline(ss, tok, ',')) gpus.push_back(atoi(tok.c_str())); }
 
+    stage("runtime + device discovery");
     for (int g : gpus) tune(g);
+    stage("Tune lines (open / close every GPU)");
     S.maxnonce = (uint64_t)c.t * c.b * c.p;
     // constants (1_9_7File.pb:4689-4712, 4759-4765)
     const Scalar two_w = hs::sc_from_u128((hs::u128)c.w * 2);
@@ -743,6 +752,7 @@ int main(int argc, char **argv)
         printf("Save BIN file:%s\n", f_g2.c_str());
     }
     if (d0) { bsgs_dev_close(d0); d0 = nullptr; }
+    stage("table + giants files (load, or build + save)");
     if (c.onlygen) { printf("onlygen: files ready\n"); return 0; }
 
     // ---- range (1_9_7File.pb:4887-4943)
@@ -815,6 +825,7 @@ int main(int argc, char **argv)
         (void)t0;
         if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }
     }
+    stage("upload, bucket lines, chain scratch, replicas");
     if (!c.joblog.empty()) { S.joblog = fopen(c.joblog.c_str(), "w"); if (!S.joblog) die("Can`t create " + c.joblog); }
     std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
     std::vector<uint8_t>().swap(g2);

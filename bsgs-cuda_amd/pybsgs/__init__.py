@@ -23,8 +23,8 @@ NATIVE_SYMBOLS = [
     "bsgs_download_g2", "bsgs_upload_htgpu", "bsgs_upload_htgpu_device", "bsgs_table_info", "bsgs_step", "bsgs_run",
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_stream", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
-    "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_broadcast_tables",
-    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_debug_xcd_profile",
+    "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_quirk_count", "bsgs_broadcast_tables",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_chain_grades", "bsgs_debug_grade_rule", "bsgs_debug_xcd_profile",
     "bsgs_table_checksum", "bsgs_debug_corrupt_table", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
 ]
 COMPAT_SYMBOLS = [
@@ -131,6 +131,7 @@ def lib():
             "bsgs_run_walk": [vp, C.c_uint64, C.c_uint32, C.POINTER(HitEx), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_float)],
             "bsgs_walk_centres": [vp, C.c_uint64, C.c_uint32, vp],
             "bsgs_set_flags": [vp, C.c_uint32],
+            "bsgs_quirk_count": [vp, C.POINTER(C.c_uint32)],
             "bsgs_broadcast_tables": [C.POINTER(vp), C.c_int],
             "bsgs_tiles_per_launch": [vp, C.POINTER(C.c_uint32)],
             "bsgs_engine_geometry": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
@@ -349,6 +350,12 @@ class Device:
     def set_flags(self, flags):
         _chk(self.L.bsgs_set_flags(self.h, flags))
 
+    def quirk_count(self):
+        """giants of the resident G2 that reference-quirk mode re-computes (their Gy trips the reference's NEGMODP)"""
+        n = C.c_uint32()
+        _chk(self.L.bsgs_quirk_count(self.h, C.byref(n)))
+        return n.value
+
     # ---- device-side tile walk: centre of tile k = P0 + k*stride, derived on the GPU ----
     def set_walk(self, p0, stride):
         _chk(self.L.bsgs_set_walk(self.h, le32(p0[0]) + le32(p0[1]), le32(stride[0]) + le32(stride[1])))
@@ -453,8 +460,12 @@ class Device:
         info, grade = (C.c_uint32 * 5)(), (C.c_float * 2)()
         self.L.bsgs_chain_placement.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
         _chk(self.L.bsgs_chain_placement(self.h, info, grade))
+        g, n, sep = (C.c_float * 64)(), C.c_uint32(), C.c_uint32()
+        self.L.bsgs_chain_grades.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _chk(self.L.bsgs_chain_grades(self.h, g, 64, C.byref(n), C.byref(sep)))
         return {"pieces": int(info[0]), "tiles_per_piece": int(info[1]), "graded": int(info[2]), "handed_back": int(info[3]),
-                "from_reserved_group": bool(info[4]), "best_grade_G_per_s": round(grade[0], 2), "worst_kept_grade_G_per_s": round(grade[1], 2)}
+                "from_reserved_group": bool(info[4]), "best_grade_G_per_s": round(grade[0], 2), "worst_kept_grade_G_per_s": round(grade[1], 2),
+                "separation_seen": bool(sep.value) or bool(info[4]), "grades_kept_first": [round(g[k], 1) for k in range(min(n.value, 64))]}
 
     def tune_placement(self, candidates=3):
         """start-up tuning of where chain scratch and bucket lines lie (bsgs_tune_placement):

@@ -102,3 +102,43 @@ def test_narrow_batching_rule(libpath):
     # nothing to do for odd / tiny / inconsistent input
     assert rule(1000, 10, 1) == 10 and rule(1 << 24, 1023, 1) == 1023 and rule(12345, 256, 1) == 256
     assert L.bsgs_debug_narrow_batching(n, 1024, 1, 256, 256, None) != 0
+
+
+def test_grader_stop_and_keep_rule_without_a_device(libpath):
+    """bsgs_debug_grade_rule = the rule alloc_graded_pieces follows (placement.hip GradeRule): when to stop drawing scratch pieces and which to keep,
+    for GPUs that show two memory classes (MI355X so far), one class only, five classes, or nothing but bad pieces."""
+    L = ctypes.CDLL(libpath)
+    L.bsgs_debug_grade_rule.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                        ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
+
+    def rule(grades, need, extra=24):
+        g = (ctypes.c_float * len(grades))(*grades)
+        drawn, sep, kept = ctypes.c_uint32(), ctypes.c_uint32(), (ctypes.c_uint32 * need)()
+        assert L.bsgs_debug_grade_rule(g, len(grades), need, extra, ctypes.byref(drawn), kept, ctypes.byref(sep)) == 0
+        return drawn.value, list(kept), bool(sep.value)
+
+    far, near, straddle = 41.8, 38.0, 40.9
+    # the usual case: the first allocations come from the lines' own group (all near), then the far group turns up: draw until `need` far ones are there
+    drawn, kept, sep = rule([near] * 6 + [far] * 10 + [near] * 20, 6)
+    assert (drawn, sorted(kept), sep) == (12, [6, 7, 8, 9, 10, 11], True)
+    # far pieces first: a separation must still be SEEN before "six within 2 % of the best" means anything -> one near piece later is enough
+    drawn, kept, sep = rule([far] * 8 + [near] + [far] * 30, 6)
+    assert (drawn, sorted(kept), sep) == (9, [0, 1, 2, 3, 4, 5], True)
+    # straddlers (2-3 % low) are not kept while better ones exist, and do not count as a separation
+    drawn, kept, sep = rule([far, straddle, far, far, straddle, far, far, near, far], 6)
+    assert sep and sorted(kept) == [0, 2, 3, 5, 6, 8] and drawn == 9
+    # ONE class only (another partition mode, or a table that fills every group evenly): after need + 12 pieces the rule gives up, keeps the FIRST `need`
+    # in allocation order -- plain allocation -- and reports that it saw no separation
+    drawn, kept, sep = rule([40.0 + 0.1 * (k % 3) for k in range(40)], 6)
+    assert (drawn, kept, sep) == (18, [0, 1, 2, 3, 4, 5], False)
+    # five classes 3 % apart: the best class is kept once six of it were seen and something 5 % lower showed up
+    five = [44.0, 42.7, 41.4, 40.1, 38.8]
+    seq = [five[k % 5] for k in range(60)]
+    drawn, kept, sep = rule(seq, 6)
+    assert sep and all(seq[k] == 44.0 for k in kept) and drawn == 26             # the sixth 44.0 is piece 25
+    # all pieces bad but one: that one sets the best, nothing else is within 2 % -> the draw runs to need + extra_max and keeps the best six there are
+    drawn, kept, sep = rule([38.0] * 3 + [42.0] + [38.0] * 40, 6, extra=10)
+    assert drawn == 16 and sep and kept[0] == 3 and len(set(kept)) == 6
+    # fewer candidates than needed: everything there is, marked
+    drawn, kept, sep = rule([41.0, 38.0], 4)
+    assert drawn == 2 and kept[2:] == [0xFFFFFFFF] * 2

@@ -137,3 +137,57 @@ def test_overflow_bound_invariant_is_checked_at_install(O):
         dev.upload_htgpu(img.tobytes(), items, w, pybsgs.TABLE_LINES64_LIST)
     dev.upload_htgpu(gpu, items, w, pybsgs.TABLE_LINES64_LIST)      # the sorted image: fine
     dev.close()
+
+
+def test_shipped_kernel_per_key_parity_at_the_reference_default_geometry(O):
+    """The reference's own defaults -t 256 -b 132 -p 400 (1_9_7File.pb:181-184): 33792 reference threads x 400 giants; the engine batches them as 16896 threads x
+    800 giants -- the only quad-chain batch length in use that is not a power of two (200 groups of four, 66 blocks per tile: not a multiple of 8, so the
+    plain block -> tile map).  Every key of 7 engine threads in 3 tiles of a walk launch, one by one, on the production instantiation; then a ONE-tile launch
+    (the reference's launch pattern) on the narrow batching this geometry gets (33792 x 400 -> 67584 x 200: 200 is still a multiple of 4)."""
+    import numpy as np
+    import pybsgs
+    from pybsgs import ecpy
+    t, b, p, w, htsz = 256, 132, 400, 1 << 25, 13
+    dev = pybsgs.Device(0)
+    A = ecpy.addpubg(w)
+    dev.generate_g2(A[0], A[1], t, b, p)
+    g2 = np.frombuffer(dev.download_g2(64 * t * b * p), dtype=np.uint8)
+    Ti, pi = dev.engine_geometry()
+    assert (Ti, pi) == (16896, 800)
+    ratio = pi // p
+    _, stride = ecpy.tile_stride(t, b, p, w)
+    p0 = ecpy.mul(0x7654321 * 2 * w + 99)
+    dev.set_walk(p0, stride)
+    NT, first = 40, 5000
+    centres = dev.walk_centres(first, NT)
+    tiles = [0, 23, NT - 1]
+    qs = [0, 255, 256, 8447, 8448, Ti - 257, Ti - 1]                 # block boundaries, the middle, the last block (66 blocks: Ti = 66 * 256)
+    keys = []
+    for tl in tiles:
+        for q in qs:
+            keys.append(O.tile_slice_keys(centres[tl], g2, t, b, p, q * ratio, (q + 1) * ratio).reshape(-1))
+    allkeys = np.concatenate(keys)
+    assert len(allkeys) == len(tiles) * len(qs) * 2 * pi
+    gpu_img, _ = O.pack_tables_from_keys(allkeys, htsz)
+    dev.upload_htgpu(gpu_img, 1 << htsz, len(allkeys), pybsgs.TABLE_LINES64)
+    dev.set_tiles_per_launch(NT)
+    hits, n, _ = dev.run_walk(first, NT, 65536)
+    assert dev.last_kernel() == "giant_pair2_kernel<2, false, true>" and dev.last_batching() == (Ti, pi) and n == len(hits)
+    got = {}
+    for tile, code, idx in hits:
+        got.setdefault(tile, set()).add((code, idx))
+    ht = np.frombuffer(gpu_img, dtype=np.uint8)
+    for tl in tiles:
+        mine = got.get(tl, set())
+        for q in qs:
+            lo, hi = q * pi, (q + 1) * pi
+            for i in range(lo, hi):
+                assert (2, i) in mine and ((1, i) in mine or (4, i) in mine), (tl, q, i)
+            ref, nref, _ = O.tile_slice_digest(centres[tl], g2, t, b, p, ht, htsz, q * ratio, (q + 1) * ratio, max_hits=8192)
+            assert sorted((c, i) for c, i in mine if lo <= i < hi) == sorted(ref), (tl, q)
+    # one tile per launch: narrow batching, same hits for that tile
+    dev.set_tiles_per_launch(0)
+    one, n1, _ = dev.run_walk(first + 23, 1, 65536)
+    assert dev.last_batching()[1] in (200, 400) and dev.last_batching()[0] * dev.last_batching()[1] == t * b * p
+    assert sorted((c, i) for _, c, i in one) == sorted(got[23])
+    dev.close()
