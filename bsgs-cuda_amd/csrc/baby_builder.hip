@@ -423,10 +423,10 @@ extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz,
     HIPCHK(bsgs_lines_malloc(d, (void **)&lines, ht_items * line_bytes));
     clk.lap(d, "allocate the bucket lines (placed)");
     hipError_t e = bsgs_big_malloc((void **)&ovf, ovf_cap * 8);
-    if (e != hipSuccess) { (void)hipFree(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)bsgs_big_free(lines); return fail(BSGS_ERR_HIP, "hipMalloc overflow list: %s", hipGetErrorString(e)); }
     uint64_t n = 0, ob = 0;
     rc = ext_build_into(d, w, htsz, lplog, lines, ovf, ovf_cap, &n, &ob);
-    if (rc) { (void)hipFree(lines); (void)hipFree(ovf); return rc; }
+    if (rc) { (void)bsgs_big_free(lines); (void)hipFree(ovf); return rc; }
     return bsgs_install_lines(d, lines, lplog, ovf, n, ht_items, w, ob);    // the engine owns both buffers now
 }
 

@@ -138,7 +138,7 @@ extern "C" int bsgs_dev_open(int device_id, bsgs_dev **out)
 static void free_table(bsgs_dev *d)
 {
     if (d->csr && d->csr_owned) (void)hipFree(d->csr);
-    if (d->lines && d->lines_owned) (void)hipFree(d->lines);
+    if (d->lines && d->lines_owned) (void)bsgs_big_free(d->lines);
     if (d->ovf && d->lines_owned) (void)hipFree(d->ovf);
     d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true; d->auto_tpl = 0;
     d->narrow_off = false;                  // memory was short for a narrow copy of the giants ONCE: another table, another try
@@ -146,7 +146,7 @@ static void free_table(bsgs_dev *d)
 void bsgs_free_table(bsgs_dev *d) { free_table(d); }
 void bsgs_free_recv(bsgs_dev *d)
 {
-    if (d->recv_lines) (void)hipFree(d->recv_lines);
+    if (d->recv_lines) (void)bsgs_big_free(d->recv_lines);
     if (d->recv_ovf) (void)hipFree(d->recv_ovf);
     d->recv_lines = d->recv_ovf = nullptr;
 }
@@ -497,7 +497,7 @@ static int build_lines(bsgs_dev *d, uint32_t layout, bool with_list)
         (void)hipFree(list);
         if (rc) { (void)hipFree(table); return rc; }
         rc = validate_ext_table(d, d->lines, lplog, table, slots, d->ht_items);      // an image with unsorted buckets (not the reference's format) ends here
-        if (rc) { (void)hipFree(table); (void)hipFree(d->lines); d->lines = nullptr; d->layout = 0; return rc; }
+        if (rc) { (void)hipFree(table); (void)bsgs_big_free(d->lines); d->lines = nullptr; d->layout = 0; return rc; }
         d->ovf = table; d->ovf_n = slots;
         if (d->csr && d->csr_owned) (void)hipFree(d->csr);
         d->csr = nullptr;                                               // borrowed images stay with the caller
@@ -1012,7 +1012,7 @@ extern "C" int bsgs_tune_placement(bsgs_dev *d, uint32_t candidates, float *ms_o
         size_t best = 0;
         for (size_t k = 1; k < ms.size(); k++) if (ms[k] < ms[best] * 0.995f) best = k;
         (void)hipStreamSynchronize(d->stream);
-        for (size_t k = 0; k < held.size(); k++) if (k != best) (void)hipFree(held[k]);
+        for (size_t k = 0; k < held.size(); k++) if (k != best) (void)bsgs_big_free(held[k]);
         d->lines = held[best];
         if (rc) return rc;
         if (ms_out) for (size_t k = 0; k < ms.size(); k++) ms_out[candidates + k] = ms[k];
@@ -1605,7 +1605,7 @@ extern "C" int bsgs_debug_realloc(bsgs_dev *d, int which, uint64_t spacer_bytes)
         void *n = nullptr;
         e = bsgs_big_malloc(&n, d->lines_bytes);
         if (e == hipSuccess) e = hipMemcpy(n, d->lines, d->lines_bytes, hipMemcpyDeviceToDevice);
-        if (e == hipSuccess) { (void)hipFree(d->lines); d->lines = (u32x4 *)n; }
+        if (e == hipSuccess) { (void)bsgs_big_free(d->lines); d->lines = (u32x4 *)n; }
     } else if (which == 1 && (d->chain || !d->chain_pieces.empty())) {
         if (d->chain) (void)hipFree(d->chain);
         free_chain_pieces(d);

@@ -96,6 +96,7 @@ struct bsgs_dev {
 // the big, long-lived device buffers (bucket lines, chain scratch, giants).  BSGS_CONTIGUOUS=1: ask for physically contiguous
 // memory first (hipDeviceMallocContiguous), plain hipMalloc when that is refused.
 hipError_t bsgs_big_malloc(void **p, size_t bytes);
+hipError_t bsgs_big_free(void *p);                           // releases what bsgs_big_malloc / bsgs_lines_malloc / the piece allocators handed out (hipMalloc'ed or chunk-mapped)
 hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes);       // bucket lines: the candidate in the gather-slow memory class (bsgs_hip.hip)
 // placement.hip
 void free_chain_pieces(bsgs_dev *d);                        // the graded pieces of the chain scratch

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -35,7 +36,7 @@ void park_release(int device)
             else k++;
         }
     }
-    for (void *p : mine) (void)hipFree(p);
+    for (void *p : mine) (void)bsgs_big_free(p);
 }
 uint64_t parked_bytes(int device)
 {
@@ -82,6 +83,68 @@ static hipError_t malloc_or_unpark(void **p, size_t bytes)
     }
     return e;
 }
+// ---- buffers composed of physical chunks (hipMemCreate + hipMemMap) ------------------------------------------------------------------------
+// Used for ONE thing: the bucket lines of a table above 40 GiB (bsgs_lines_malloc), where the placement needs every free 4 GiB chunk graded and
+// the chosen ones in one contiguous range.  With hipMalloc that meant: allocate all pieces, free most of them, wait until the driver has wiped
+// the ~200 GiB handed back (3.8 s at -w 34: profiles/r06e_*), allocate the range.  Chunks taken as physical handles are graded through a
+// temporary mapping and then simply mapped where they are wanted: nothing is freed, nothing is wiped.  Every pointer handed out here is
+// registered, so that one release call (bsgs_big_free) serves both kinds of memory.
+struct VmBuf { size_t bytes; size_t chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+// Addresses.  Two facts of this stack, both measured (tools/experiments/vm_hint.hip, vm_release.hip; profiles/r06m_*):
+//  * the memory of a released chunk comes back only when its ADDRESS RESERVATION is freed (hipMemUnmap + hipMemRelease inside a reservation that
+//    lives on return nothing), so every mapping has a reservation of its own, freed with it;
+//  * a freed reservation is handed out again at the very same address by the next hipMemAddressReserve, and a NEW mapping at a just-unmapped
+//    address faults (the second engine of a two-engine host died mapping its chunks moments after the first had released some of its own).
+// hipMemAddressReserve honours an address hint, so reservations are asked for at addresses that only ever go UP, in a part of the address space
+// the runtime does not use on its own: no address is mapped twice in the life of the process.
+static std::mutex g_vm_addr_mu;
+static uintptr_t g_vm_cursor = 0x200000000000ull;                    // 32 TiB; the runtime's own reservations sit above 0x7000...
+static void *vm_fresh_reserve(size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_vm_addr_mu);
+    const size_t span = (bytes + (4ull << 30) - 1) & ~((4ull << 30) - 1);
+    for (int tries = 0; tries < 16; tries++) {
+        void *p = nullptr;
+        const uintptr_t hint = g_vm_cursor;
+        g_vm_cursor += span;
+        if (hipMemAddressReserve(&p, bytes, 0, (void *)hint, 0) != hipSuccess) { (void)hipGetLastError(); g_vm_cursor += 1ull << 40; continue; }
+        if ((uintptr_t)p == hint) return p;
+        (void)hipMemAddressFree(p, bytes);                           // somebody lives there: the runtime chose an address of its own, which may be a recycled one
+        g_vm_cursor += 1ull << 40;
+    }
+    return nullptr;
+}
+static std::mutex g_vm_mu;
+static std::map<void *, VmBuf> g_vm;
+static void vm_unmap_release(void *va, const VmBuf &b)
+{
+    for (size_t k = 0; k < b.handles.size(); k++) {
+        (void)hipMemUnmap((char *)va + k * b.chunk, b.chunk);
+        (void)hipMemRelease(b.handles[k]);
+    }
+    (void)hipMemAddressFree(va, b.bytes);
+}
+hipError_t bsgs_big_free(void *p)
+{
+    if (!p) return hipSuccess;
+    VmBuf b;
+    bool vm = false;
+    {
+        std::lock_guard<std::mutex> lk(g_vm_mu);
+        auto it = g_vm.find(p);
+        if (it != g_vm.end()) { b = it->second; g_vm.erase(it); vm = true; }
+    }
+    if (!vm) return hipFree(p);
+    (void)hipDeviceSynchronize();
+    vm_unmap_release(p, b);
+    return hipSuccess;
+}
+static void vm_register(void *va, size_t bytes, size_t chunk, std::vector<hipMemGenericAllocationHandle_t> handles)
+{
+    std::lock_guard<std::mutex> lk(g_vm_mu);
+    g_vm[va] = VmBuf{bytes, chunk, std::move(handles)};
+}
+
 hipError_t bsgs_big_malloc(void **p, size_t bytes)
 {
     // BSGS_CONTIGUOUS=1 asks for physically contiguous VRAM first (large page-table fragments).  It was tried as an explanation
@@ -177,12 +240,12 @@ struct PieceGrader {
 void release_grader(bsgs_dev *d) { PieceGrader::release(d); }
 void free_reserve(bsgs_dev *d)
 {
-    for (void *p : d->group0_reserve) (void)hipFree(p);
+    for (void *p : d->group0_reserve) (void)bsgs_big_free(p);
     d->group0_reserve.clear();
 }
 void free_chain_pieces(bsgs_dev *d)
 {
-    for (u32x4 *p : d->chain_pieces) (void)hipFree(p);
+    for (u32x4 *p : d->chain_pieces) (void)bsgs_big_free(p);
     d->chain_pieces.clear();
     d->chain_piece_bytes = 0;
 }
@@ -236,7 +299,10 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
         d->chain_pieces.clear();
         for (size_t k = 0; k < npieces; k++) { d->chain_pieces.push_back((u32x4 *)d->group0_reserve.back()); d->group0_reserve.pop_back(); }
         std::sort(d->chain_pieces.begin(), d->chain_pieces.end());
-        free_reserve(d);                                          // what the scratch does not need goes back to the driver
+        // what the scratch does not need is PARKED (counted as available, released the moment an allocation needs it): handing it back costs a wipe -- 0.2 s
+        // per 4 GiB chunk, synchronously, for chunk-mapped memory -- that a start-up should not pay
+        for (void *p : d->group0_reserve) park(d->id, p, d->group0_piece_bytes);
+        d->group0_reserve.clear();
         d->chain_graded = d->group0_graded; d->chain_rejected = d->group0_graded - (uint32_t)npieces;
         d->chain_grade_best = d->group0_grade_lo; d->chain_grade_worst = d->group0_grade_hi;
         d->chain_from_reserve = 1; d->chain_separated = 1; d->chain_grades.clear();
@@ -265,7 +331,7 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
         cands.push_back({p, g});
         grades.push_back(g);
     }
-    if (cands.size() < npieces) { for (const Cand &c : cands) (void)hipFree(c.p); return false; }
+    if (cands.size() < npieces) { for (const Cand &c : cands) (void)bsgs_big_free(c.p); return false; }
     // keep by the rule: the best `npieces` when a separation was seen, the first `npieces` drawn (= plain allocation) when the grades say nothing
     const bool sep = can_grade && GradeRule::separated(grades.data(), grades.size());
     {
@@ -290,7 +356,7 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
     {
         size_t fr = 0, tot = 0;
         const bool plenty = hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= (96ull << 30);
-        for (size_t k = npieces; k < cands.size(); k++) { if (plenty) park(d->id, cands[k].p, piece_bytes); else (void)hipFree(cands[k].p); }
+        for (size_t k = npieces; k < cands.size(); k++) { if (plenty) park(d->id, cands[k].p, piece_bytes); else (void)bsgs_big_free(cands[k].p); }
     }
     d->chain_graded = (uint32_t)cands.size(); d->chain_rejected = (uint32_t)(cands.size() - npieces);
     d->chain_grade_best = d->chain_grade_worst = cands[0].g;
@@ -303,6 +369,145 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
     return true;
 }
 
+// Large table, by physical chunks: every free 4 GiB chunk is taken as a handle, mapped at an address of its own and graded against the grader's
+// buffers ("group 0" = the memory group THEY lie in); the lines are then composed of chunks that are NOT in group 0 (best grades first), up to 24
+// group-0 chunks stay mapped as they are -- the pieces the chain scratch will be taken from (alloc_graded_pieces) -- and the rest is released.
+static hipError_t lines_malloc_chunks(bsgs_dev *d, PieceGrader &G, void **out, size_t bytes)
+{
+    const size_t chunk = 4ull << 30;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = d->id;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran || chunk % gran) return hipErrorNotSupported;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    struct C { hipMemGenericAllocationHandle_t h; void *va; float g; };
+    std::vector<C> all;
+    const size_t need = (bytes + chunk - 1) / chunk;
+    const bool verbose = getenv("BSGS_BUILD_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    auto drop = [&](C &c) { if (c.va) { (void)hipMemUnmap(c.va, chunk); (void)hipMemAddressFree(c.va, chunk); } (void)hipMemRelease(c.h); c.va = nullptr; };
+    for (void *p : d->group0_reserve) park(d->id, p, d->group0_piece_bytes);
+    d->group0_reserve.clear();
+    // chunks this process parked earlier (an earlier table, the other engine on this GPU) are candidates like any other: already taken, already mapped
+    std::vector<C> adopted;
+    {
+        std::vector<Parked> mine;
+        {
+            std::lock_guard<std::mutex> lk(g_park_mu);
+            for (size_t k = 0; k < g_parked.size();) {
+                if (g_parked[k].device == d->id) { mine.push_back(g_parked[k]); g_parked[k] = g_parked.back(); g_parked.pop_back(); }
+                else k++;
+            }
+        }
+        for (const Parked &x : mine) {
+            bool vm = false;
+            C c{};
+            if (x.bytes == chunk) {
+                std::lock_guard<std::mutex> lk(g_vm_mu);
+                auto it = g_vm.find(x.p);
+                if (it != g_vm.end() && it->second.handles.size() == 1 && it->second.bytes == chunk) { c.h = it->second.handles[0]; c.va = x.p; g_vm.erase(it); vm = true; }
+            }
+            if (vm) adopted.push_back(c);
+            else (void)bsgs_big_free(x.p);
+        }
+    }
+    float top = 0.f;
+    for (;;) {
+        size_t fr = 0, tot = 0;
+        C c{};
+        if (!adopted.empty()) {
+            c = adopted.back(); adopted.pop_back();
+            c.g = G.grade(c.va, chunk);
+            top = std::max(top, c.g);
+            all.push_back(c);
+            size_t far = 0, near = 0;
+            for (const C &x : all) { if (x.g <= 0.93f * top) near++; else far++; }
+            if (far >= need && (near >= 8 || all.size() >= need + 24)) break;
+            continue;
+        }
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < chunk + (2ull << 30)) break;
+        if (hipMemCreate(&c.h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (!(c.va = vm_fresh_reserve(chunk))) { (void)hipMemRelease(c.h); break; }
+        if (hipMemMap(c.va, chunk, 0, c.h, 0) != hipSuccess || hipMemSetAccess(c.va, chunk, &acc, 1) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipMemAddressFree(c.va, chunk); (void)hipMemRelease(c.h);
+            break;
+        }
+        c.g = G.grade(c.va, chunk);
+        top = std::max(top, c.g);
+        all.push_back(c);
+        // enough: `need` chunks outside group 0 for the lines and eight inside it for the chain scratch (24 GiB at the headline geometry = six).  Taking
+        // a chunk costs up to 50 ms (the driver clears memory it hands out): the rest of the free memory is left alone
+        size_t far = 0, near = 0;
+        for (const C &x : all) { if (x.g <= 0.93f * top) near++; else far++; }
+        if (far >= need && (near >= 8 || all.size() >= need + 24)) break;        // (a second engine on the GPU finds most of group 0 taken: it does not go on for ever)
+    }
+    (void)hipStreamSynchronize(d->stream);
+    for (C &c : adopted) { vm_register(c.va, chunk, chunk, {c.h}); park(d->id, c.va, chunk); }      // not looked at: parked again
+    adopted.clear();
+    if (all.size() < need) { for (C &c : all) drop(c); return hipErrorOutOfMemory; }
+    // lines: the `need` chunks furthest from group 0 (highest grades); group 0 = grade <= 0.93 x top
+    std::vector<size_t> order(all.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return all[a].g > all[b].g; });
+    std::vector<bool> used(all.size(), false);
+    void *big = vm_fresh_reserve(need * chunk);
+    if (!big) { for (C &c : all) drop(c); return hipErrorOutOfMemory; }
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    size_t in_group0 = 0;
+    bool ok = true;
+    for (size_t k = 0; k < need && ok; k++) {
+        C &c = all[order[k]];
+        used[order[k]] = true;
+        in_group0 += c.g <= 0.93f * top;
+        // a chunk moves: its temporary mapping goes (address and all: a second mapping at a just-unmapped address faults), then it is mapped into the range
+        ok = hipMemUnmap(c.va, chunk) == hipSuccess && hipMemAddressFree(c.va, chunk) == hipSuccess;
+        c.va = nullptr;
+        ok = ok && hipMemMap((char *)big + k * chunk, chunk, 0, c.h, 0) == hipSuccess;
+        if (ok) handles.push_back(c.h);
+    }
+    ok = ok && hipMemSetAccess(big, need * chunk, &acc, 1) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (size_t k = 0; k < handles.size(); k++) (void)hipMemUnmap((char *)big + k * chunk, chunk);
+        (void)hipMemAddressFree(big, need * chunk);
+        for (size_t k = 0; k < all.size(); k++) { if (used[k]) { all[k].va = nullptr; (void)hipMemRelease(all[k].h); } else drop(all[k]); }
+        return hipErrorUnknown;
+    }
+    vm_register(big, need * chunk, chunk, handles);
+    // the reserve for the chain scratch: group-0 chunks that the lines did not need, as mapped pieces; everything else goes back
+    float lo = 1e30f, hi = 0.f;
+    size_t released = 0;
+    for (size_t k = 0; k < all.size(); k++) {
+        if (used[k]) continue;
+        C &c = all[k];
+        if (c.g <= 0.93f * top && d->group0_reserve.size() < 24) {
+            vm_register(c.va, chunk, chunk, {c.h});
+            d->group0_reserve.push_back(c.va);
+            lo = std::min(lo, c.g); hi = std::max(hi, c.g);
+        } else {
+            // not needed: parked, not released -- memory that is handed back is wiped before anyone can have it again, and an allocation right after this one
+            // (the overflow set, the chain scratch of a second engine) would find the GPU "full"; parked chunks are released the moment an allocation fails
+            vm_register(c.va, chunk, chunk, {c.h});
+            park(d->id, c.va, chunk);
+            released++;
+        }
+    }
+    d->group0_piece_bytes = chunk; d->group0_graded = (uint32_t)all.size(); d->group0_grade_lo = lo > 1e29f ? 0.f : lo; d->group0_grade_hi = hi;
+    if (verbose || getenv("BSGS_TUNE_VERBOSE"))
+        fprintf(stderr, "[place] %.0f GiB of lines composed of %zu chunks of 4 GiB (%zu of them in the grader's group), %zu chunks graded (top %.1f) in %.0f ms, "
+                        "%zu of group 0 held back for the chain scratch (%.1f...%.1f), %zu parked\n", bytes / 1073741824.0, need, in_group0, all.size(), top, ms_since(t0),
+                d->group0_reserve.size(), d->group0_grade_lo, hi, released);
+    *out = big;
+    g_alloc_plain += bytes;
+    return hipSuccess;
+}
+
 // The bucket lines (see "placement by grade" above): plain up to 40 GiB; larger tables get one memory group reserved for the chain scratch first.
 hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
 {
@@ -310,6 +515,11 @@ hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
     if (!on || !d || bytes <= (40ull << 30)) return bsgs_big_malloc(out, bytes);      // anywhere: the scratch pieces are graded against these very lines
     PieceGrader G(d);
     if (!G.init()) return bsgs_big_malloc(out, bytes);
+    static const bool chunks_on = !(getenv("BSGS_CHUNK_LINES") && atoi(getenv("BSGS_CHUNK_LINES")) == 0);
+    if (chunks_on) {
+        if (lines_malloc_chunks(d, G, out, bytes) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();                                  // the virtual-memory calls are not there / failed: the hipMalloc walk below
+    }
     {
         // Large table: walk through the free memory in 4 GiB pieces, keep every piece of group 0 (low grade) as the reserve the chain
         // scratch will be taken from, give the others back, THEN allocate the lines: they land in the other two groups.
