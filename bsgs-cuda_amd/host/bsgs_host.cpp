@@ -726,6 +726,10 @@ int main(int argc, char **argv)
     const std::string f_gpu = stem + "_htGPUv0.BIN", f_cpu = stem + "_htCPUv0.BIN";
     const std::string f_g2 = c.dir + "/" + std::to_string(c.t) + "_" + std::to_string(c.b) + "_" + std::to_string(c.p) + "_" + std::to_string(c.w) + "_g2.BIN";
     std::vector<uint8_t> htgpu, g2;
+    // files that were just generated are written by background threads while the start-up goes on (upload, bucket lines, scratch): the buffers they read
+    // stay alive until `flush_writers` -- before the staging copies are released, and before any return
+    std::vector<std::thread> writers;
+    auto flush_writers = [&]() { for (auto &w : writers) w.join(); writers.clear(); };
     const uint64_t gpu_bytes = 4 * (ht_items + 1) + 4 * c.w, cpu_bytes = 4 * (ht_items + 1) + 8 * c.w, g2_bytes = 64 * S.maxnonce;
     bsgs_dev *d0 = nullptr;
     auto dev0 = [&]() { if (!d0) CK(bsgs_dev_open(gpus[0], &d0)); return d0; };
@@ -736,8 +740,8 @@ int main(int argc, char **argv)
         const auto t0 = std::chrono::steady_clock::now();
         htgpu.resize(gpu_bytes); S.htcpu.resize(cpu_bytes);
         CK(bsgs_build_baby_tables(dev0(), c.w, c.htsz, htgpu.data(), S.htcpu.data(), BSGS_NO_INSTALL));
-        write_file(f_cpu, S.htcpu.data(), cpu_bytes);
-        write_file(f_gpu, htgpu.data(), gpu_bytes);
+        writers.emplace_back([&]() { write_file(f_cpu, S.htcpu.data(), cpu_bytes); });
+        writers.emplace_back([&]() { write_file(f_gpu, htgpu.data(), gpu_bytes); });
         printf("Done in %.1fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     if (read_file(f_g2, g2, g2_bytes)) printf("Load BIN file:%s\n", f_g2.c_str());
@@ -748,12 +752,12 @@ int main(int argc, char **argv)
         CK(bsgs_generate_g2(dev0(), axy, c.t, c.b, c.p));
         g2.resize(g2_bytes);
         CK(bsgs_download_g2(dev0(), g2.data(), g2_bytes));
-        write_file(f_g2, g2.data(), g2_bytes);
+        writers.emplace_back([&]() { write_file(f_g2, g2.data(), g2_bytes); });
         printf("Save BIN file:%s\n", f_g2.c_str());
     }
     if (d0) { bsgs_dev_close(d0); d0 = nullptr; }
     stage("table + giants files (load, or build + save)");
-    if (c.onlygen) { printf("onlygen: files ready\n"); return 0; }
+    if (c.onlygen) { flush_writers(); printf("onlygen: files ready\n"); return 0; }
 
     // ---- range (1_9_7File.pb:4887-4943)
     if (!hs::fe_from_hex(S.start, c.pk) || hs::fe_is_zero(S.start)) die("Start range can`t be zero");
@@ -827,6 +831,8 @@ int main(int argc, char **argv)
     }
     stage("upload, bucket lines, chain scratch, replicas");
     if (!c.joblog.empty()) { S.joblog = fopen(c.joblog.c_str(), "w"); if (!S.joblog) die("Can`t create " + c.joblog); }
+    flush_writers();
+    stage("files on disk (written behind the start-up)");
     std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
     std::vector<uint8_t>().swap(g2);
 
