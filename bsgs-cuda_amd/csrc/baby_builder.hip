@@ -11,6 +11,7 @@
 // The images are byte-identical to the reference's files for the same (w, htsz) (tests compare with the oracle
 // and with the sha256 digests of tests/golden/cfg1_digests.json).
 #include "bsgs_internal.h"
+#include "support_kernels.hip.h"
 #include "host_secp.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>

@@ -2,6 +2,7 @@
 // Build: see ../Makefile (hipcc --offload-arch=gfx950 -shared -fPIC).  No CPU fallback exists: every
 // entry point fails with BSGS_ERR_HIP when no gfx950 device / runtime is available.
 #include "bsgs_internal.h"
+#include "support_kernels.hip.h"
 #include "host_secp.h"
 
 #include <algorithm>
