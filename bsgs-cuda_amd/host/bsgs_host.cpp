@@ -202,6 +202,8 @@ struct PendingHit { uint32_t code, idx; Tile tile; };
 struct Shared {
     Config cfg;
     uint64_t maxnonce = 0;
+    double job_tiles = 0.0;                        // tiles in the range of the current job (0 = unbounded / unknown), and the engines that share it
+    int ngpus = 1;
     Scalar center_big, gstep, start, width;      // p*w ; 4*maxnonce*w ; -pk ; pke-pk
     bool end_range = false, past_end = false;
     Affine addpubg, center, pubadd, start_neg;   // -(2w)G ; -(p*w)G ; -(gstep)G ; -(start)G
@@ -216,6 +218,7 @@ struct Shared {
     std::deque<PendingHit> checker;
     std::atomic<bool> quit{false}, all_done{false};
     std::atomic<uint64_t> steps_done{0}, tiles_done{0};
+    std::atomic<uint64_t> hits_pushed{0};                   // hits handed to the checker threads
     std::atomic<uint64_t> hits_checked{0}, checker_ns{0};   // resolver load: false positives cost CPU (a small BSGS each with an extended table)
     std::atomic<int> gpus_finished{0};
     std::mutex done_mutex;
@@ -417,12 +420,12 @@ static void checker_thread(Shared *S)
         const auto tc0 = std::chrono::steady_clock::now();
         const bool solved = resolve_hit(*S, hit, key);
         S->checker_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tc0).count();
-        S->hits_checked++;
         if (solved) {
             std::lock_guard<std::mutex> lk(S->chk_mutex);
             S->winkey = key; S->found = true;
             S->quit.store(true);
         }
+        S->hits_checked++;                      // after `quit`: a driver thread that waits for its hits to be resolved (short jobs) sees the verdict with the count
     }
 }
 
@@ -500,7 +503,12 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
 {
     uint32_t tpl = 48;
     if (bsgs_tiles_per_launch(dev, &tpl) != BSGS_OK || !tpl) tpl = 48;
-    const size_t batch = tpl;                     // one launch (the engine's choice: 48..192 tiles); a found key stops the job at the next batch boundary
+    // One batch = one launch (the engine's choice: 48..192 tiles); a found key stops the job at the next batch boundary.  A job that is only a launch or two
+    // long (BASELINE config 4: a 64-bit range at -w 30 is 129 tiles) would always run to its end that way -- the reference, one tile per launch, stops at the
+    // hit (1_9_7File.pb:2442-2523) -- so such a job is dealt in about six batches per GPU (not below 16 tiles: the narrow batchings keep small launches at
+    // 36-38 G): with the key anywhere in the range 0.6 of the work is done on average instead of all of it.
+    size_t batch = tpl;
+    if (S->job_tiles && S->job_tiles < 4.0 * tpl * S->ngpus) batch = (size_t)std::min<double>(tpl, std::max(16.0, std::ceil(S->job_tiles / (6.0 * S->ngpus))));
     std::vector<Tile> tiles;
     std::vector<uint8_t> centres;
     std::vector<bsgs_hit_ex> hits(65536);
@@ -508,6 +516,7 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
         if (!n) return;
         std::lock_guard<std::mutex> lk(S->chk_mutex);
         for (uint32_t i = 0; i < n; i++) S->checker.push_back({h[i].code, h[i].idx, base[h[i].tile]});
+        S->hits_pushed += n;
         S->chk_cv.notify_all();
     };
     // tiles [i0, i0 + n) of the current batch with centres added on the host and uploaded (the reference's way: -hostcentres, and the
@@ -543,6 +552,9 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
         else push_hits(hits.data(), nh, tiles.data());
         S->steps_done += 2 * S->maxnonce * n;
         S->tiles_done += n;
+        // a short job (batches smaller than a launch: see above) does not run ahead of its checker: the next batch is dispensed once this one's hits are resolved
+        // (microseconds each with the htCPU table), so that the batch that holds the key is the last one
+        if (batch < tpl) while (!S->quit.load() && S->hits_checked.load() < S->hits_pushed.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
         {
             std::lock_guard<std::mutex> lk(S->inflight_mutex);
             S->inflight_valid[slot] = false;
@@ -878,7 +890,12 @@ int main(int argc, char **argv)
             }
         }
         S.past_end = false;
-        S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0; S.hits_checked = 0; S.checker_ns = 0;
+        {   // width / gstep as floating point: how many tiles the range is long (the batches of a short job are sized by it: gpu_thread)
+            auto as_double = [](const Scalar &v) { double r = 0.0; for (int l = 3; l >= 0; l--) r = r * 18446744073709551616.0 + (double)v.l[l]; return r; };
+            S.job_tiles = S.end_range ? as_double(S.width) / as_double(S.gstep) + 1.0 : 0.0;
+            S.ngpus = (int)gpus.size();
+        }
+        S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0; S.hits_checked = 0; S.hits_pushed = 0; S.checker_ns = 0;
         const auto t0 = std::chrono::steady_clock::now();
         Scalar one = hs::fe_from_u64(1), two = hs::fe_from_u64(2);
         Scalar trivial;                                                 // keys 1 and 2 are answered without search (5069-5107)
