@@ -369,9 +369,10 @@ bool alloc_graded_pieces(bsgs_dev *d, size_t npieces, uint64_t piece_bytes)
     return true;
 }
 
-// Large table, by physical chunks: every free 4 GiB chunk is taken as a handle, mapped at an address of its own and graded against the grader's
-// buffers ("group 0" = the memory group THEY lie in); the lines are then composed of chunks that are NOT in group 0 (best grades first), up to 24
-// group-0 chunks stay mapped as they are -- the pieces the chain scratch will be taken from (alloc_graded_pieces) -- and the rest is released.
+// Large table, by physical chunks: free 4 GiB chunks are taken as handles one at a time (chunks this process parked earlier first), mapped at an address
+// of their own and graded against the grader's buffers ("group 0" = the memory group THEY lie in), until enough were seen: as many outside group 0 as the
+// lines need, eight inside it.  The lines are then composed of the chunks furthest from group 0, up to 24 group-0 chunks stay mapped as they are -- the
+// pieces the chain scratch will be taken from (alloc_graded_pieces) -- and what is left over is parked (released the moment an allocation needs it).
 static hipError_t lines_malloc_chunks(bsgs_dev *d, PieceGrader &G, void **out, size_t bytes)
 {
     const size_t chunk = 4ull << 30;
