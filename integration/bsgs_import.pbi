@@ -90,4 +90,7 @@ CompilerEndIf
   bsgs_build_baby_table_ext_device(dev.i, w.q, htsz.l, layout.l, lines.i, ovf.i, ovf_cap.q, *ovf_n, *overflow_buckets)   ; ... rank 0 builds into its pair
   bsgs_install_table_ext_device(dev.i, lines.i, ovf.i, ovf_n.q, overflow_buckets.q, w.q, htsz.l, layout.l)                ; ... every rank installs its pair after the broadcast
   bsgs_compat_stats_ex(*launches, *served, *batches, *wasted_tiles)  ; route A: how the adaptive predicted batches fared
+  bsgs_table_checksum(dev.i, *sums4)                                 ; round 4: 64-bit sums of lines / overflow set / image / giants, computed on the GPU: equal across replicas (compare after bsgs_broadcast_tables)
+  bsgs_build_info()                                                  ; -> *ascii: the -D switches of the library; must be empty for a library that searches ("WRONG-RESULTS:..." = a timing experiment)
+  bsgs_quirk_count(dev.i, *listed)                                   ; how many giants reference-quirk mode (bsgs_set_flags 1) re-computes after every launch
 EndImport
