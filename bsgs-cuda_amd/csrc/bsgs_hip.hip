@@ -90,7 +90,9 @@ extern "C" const char *bsgs_build_info(void)
         if (BSGS_NT_CHAIN != 1) add("BSGS_NT_CHAIN=" BSGS_STR(BSGS_NT_CHAIN));
         if (BSGS_NT_LINES != 0) add("BSGS_NT_LINES=" BSGS_STR(BSGS_NT_LINES));
         if (BSGS_PROBE_CPOL != 2) add("BSGS_PROBE_CPOL=" BSGS_STR(BSGS_PROBE_CPOL));
-        if (BSGS_SLICE_GATE != 0) add("BSGS_SLICE_GATE=" BSGS_STR(BSGS_SLICE_GATE));
+#ifdef BSGS_SLICE_GATE
+        add("BSGS_SLICE_GATE=" BSGS_STR(BSGS_SLICE_GATE));
+#endif
 #undef SW
 #undef WRONG
         return s;
@@ -184,7 +186,6 @@ extern "C" int bsgs_dev_close(bsgs_dev *d)
     if (d->cen_pin) (void)hipHostFree(d->cen_pin);
     if (d->walk_table) (void)hipFree(d->walk_table);
     if (d->digest) (void)hipFree(d->digest);
-    if (d->gate) (void)hipFree(d->gate);
     (void)hipEventDestroy(d->ev0); (void)hipEventDestroy(d->ev1);
     (void)hipStreamDestroy(d->stream);
     delete d;
@@ -723,18 +724,6 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = pi; A.T = Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
     A.debug_flags = d->debug_flags; A.pad0 = 0;
-#ifdef BSGS_G2_CACHED_CEILING
-    A.pad0 = 1;                          // experiment build only (results WRONG): every giant read hits one cached KiB per wave
-#endif
-    A.gate = nullptr;
-#if BSGS_SLICE_GATE
-    if (chain_group(d, pi) == 4 && !d->debug_flags && !d->phase_probe) {      // experiment build (exact results): progress words of the slice gate, zeroed per launch
-        const size_t words = (size_t)(((Ti + d->block_size - 1) / d->block_size) * ntiles);
-        if (d->gate_words < words) { if (d->gate) (void)hipFree(d->gate); d->gate = nullptr; HIPCHK(hipMalloc(&d->gate, words * 4)); d->gate_words = words; }
-        HIPCHK(hipMemsetAsync(d->gate, 0, words * 4, st));
-        A.gate = d->gate;
-    }
-#endif
     A.centres_dev = centres_dev;
     A.digest = d->digest ? d->digest + (uint64_t)seq * Ti * 2 : nullptr;
     A.chain_pad = d->chain_pad; A.chain_mode = 0;

@@ -85,8 +85,6 @@ struct bsgs_dev {
     u32 *quirk_list = nullptr;             // device: giants whose Gy trips the reference's NEGMODP (BSGS_FLAG_REFERENCE_QUIRKS)
     std::vector<uint32_t> quirk_host;      // the same, sorted, for the hit filter of bsgs_collect
     bool quirk_ready = false;
-    u32 *gate = nullptr;                   // BSGS_SLICE_GATE builds only: progress words of the slice gate
-    size_t gate_words = 0;
     u64 *digest = nullptr;                 // bsgs_run_digest: [tile][Ti][2]
     uint64_t digest_bytes = 0;
     // receive buffers of an extended table that arrives by broadcast (bsgs_alloc_table_ext_recv): allocated like the engine's own

@@ -59,9 +59,9 @@ def test_product_does_not_link_or_import_the_oracle(libpath):
                 assert "liboracle" not in src and "oracle_lib" not in src and "curve64_ref" not in src, f
 
 
-def test_shipped_library_has_no_experiment_switch_and_ceilings_need_one(libpath, tmp_path):
+def test_shipped_library_has_no_experiment_switch_and_the_shipped_source_has_none_to_offer(libpath, tmp_path):
     """bsgs_build_info() of the library the tests (and the driver) load is empty: no A/B switch, above all none of the *_CEILING timing
-    experiments, which return wrong results; and such a switch does not compile without -DBSGS_EXPERIMENT"""
+    experiments, which return wrong results; and the shipped source refuses such a switch (they live in a patch that is applied to a copy)"""
     L = ctypes.CDLL(libpath)
     L.bsgs_build_info.restype = ctypes.c_char_p
     assert L.bsgs_build_info() == b"", L.bsgs_build_info()
@@ -70,9 +70,31 @@ def test_shipped_library_has_no_experiment_switch_and_ceilings_need_one(libpath,
         pytest.skip("no hipcc")
     src = tmp_path / "guard.hip"
     src.write_text('#include "%s"\n' % os.path.join(ROOT, "bsgs-cuda_amd", "csrc", "giant_kernel.hip.h"))
-    for sw in ("BSGS_NOCHAIN_CEILING", "BSGS_G2_CACHED_CEILING", "BSGS_NO_OVF_CEILING"):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-D" + sw, str(src)], capture_output=True, text=True)
-        assert r.returncode != 0 and "BSGS_EXPERIMENT" in r.stderr, (sw, r.stderr[-300:])
+    for sw in ("BSGS_NOCHAIN_CEILING", "BSGS_G2_CACHED_CEILING", "BSGS_NO_OVF_CEILING", "BSGS_SLICE_GATE=64", "BSGS_FULL_X"):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-D" + sw, "-DBSGS_EXPERIMENT", str(src)], capture_output=True, text=True)
+        assert r.returncode != 0 and "build_experiment.sh" in r.stderr, (sw, r.stderr[-300:])
+
+
+def test_tile_kernel_carries_no_experiment_branches_and_the_experiment_patch_still_applies(tmp_path):
+    """the hot function giant_pair2_kernel is free of preprocessor branches (the ceilings, G2_VARY and the slice gate moved to
+    tools/experiments/tile_kernel_experiments.patch); the patch must keep applying to the shipped sources, or tools/fetch_breakdown.py loses its
+    two experiment libraries."""
+    src = open(os.path.join(ROOT, "bsgs-cuda_amd", "csrc", "giant_kernel.hip.h")).read()
+    a = src.index("giant_pair2_kernel(const TileArgs A)")
+    body = src[a:]
+    assert not re.search(r"^\s*#\s*(if|ifdef|ifndef|elif|else|endif)\b", body, flags=re.M), "preprocessor branch inside the tile kernel"
+    for word in ("CEILING", "G2_VARY", "gate_step", "BSGS_SLICE_GATE"):
+        assert word not in body, word
+    work = tmp_path / "bsgs-cuda_amd"
+    (work / "csrc").mkdir(parents=True)
+    for f in ("giant_kernel.hip.h", "bsgs_hip.hip", "bsgs_internal.h"):
+        (work / "csrc" / f).write_text(open(os.path.join(ROOT, "bsgs-cuda_amd", "csrc", f)).read())
+    patch = os.path.join(ROOT, "tools", "experiments", "tile_kernel_experiments.patch")
+    r = subprocess.run(["patch", "-p1", "-d", str(work), "-i", patch], capture_output=True, text=True)
+    assert r.returncode == 0 and ".rej" not in r.stdout, r.stdout[-600:] + r.stderr[-300:]
+    patched = (work / "csrc" / "giant_kernel.hip.h").read_text()
+    for word in ("BSGS_NOCHAIN_CEILING", "BSGS_G2_CACHED_CEILING", "BSGS_SLICE_GATE", "BSGS_G2_VARY"):
+        assert word in patched, word
 
 
 def test_narrow_batching_rule(libpath):
