@@ -24,12 +24,13 @@
 // Point generation: thread tid walks S_tid + j*(T*G), S_tid = (first + tid)*G, j = 0..pi-1, with the tile kernel's batched inverse over its pi
 // points, and hands the 64-bit key (low 64 bits of x) of point number first + j*T + tid to a SINK:
 //   SINK 0: keys[j*T + tid] = bucket << 32 | hash, pos[j*T + tid] = its position (the reference-format images need the positions: sorted next);
-//   SINK 2 / 3: straight into 64 / 128-byte bucket lines (ext_scatter_kernel's claim-a-slot atomic, fused: no key array, and the memory-bound
+//   SINK 2 / 3: straight into 64 / 128-byte bucket lines (one claim-a-slot atomic per key, fused into the generator: no key array, and the memory-bound
 //   scatter overlaps with the arithmetic of the other waves).  The slot an atomic returns is used one point LATER, so the wave never waits for it.
 // Only indices < count are produced.  helper[j-1] = j*(T*G) (uniform: scalar loads); chain = [pi][2][T] scratch.
 struct KeySink {
     u64 *keys; u32 *pos; u32 pos_base;  // SINK 0: sort key (bucket << 32 | hash) and position of point number idx (197:2561, 2583, 1221)
-    u32 *lines; u64 *ovf; u64 ovf_cap; unsigned long long *counters; u32 mask;      // SINK 2 / 3 (as ext_scatter_kernel)
+    u32 *lines; u64 *ovf; u64 ovf_cap; unsigned long long *counters; u32 mask;      // SINK 2 / 3: the line of bucket b counts its arrivals in word 0
+    u32 mul;                            // 0: bucket = x & mask ; M: bucket = floor(xlo * M / 2^32) (any number of buckets: giant_kernel.hip.h bucket_of)
 };
 template <int SINK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) baby_keys_kernel(const u32x4 *__restrict__ helper, const u32x4 *__restrict__ bases, const KeySink K,
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (idx >= count) return;
         if (SINK == 0) { K.keys[idx] = ((u64)((u32)key & K.mask) << 32) | (key >> 32); K.pos[idx] = K.pos_base + (u32)idx; return; }
         settle();
-        pend_bucket = (u32)key & K.mask;
+        pend_bucket = K.mul ? __umulhi((u32)key, K.mul) : ((u32)key & K.mask);
         pend_hash = (u32)(key >> 32);
         pend_line = K.lines + pend_bucket * WORDS;
         pend_slot = atomicAdd(pend_line, 1u);
@@ -261,25 +262,36 @@ static double expected_overflow_entries(double lambda, unsigned cap, double buck
     return e * buckets;
 }
 
+// `htsz` of the extended-table entry points: 1..31 = 2^htsz buckets (bucket = x & mask, like the reference's tables); a value above 31 IS the number of
+// buckets (any number below 2^32, 128-byte lines: bucket = floor(xlo * buckets / 2^32)) -- what lets a table fill the HBM there is (include/bsgs_hip.h)
+static uint64_t ext_buckets(uint32_t htsz) { return htsz <= 31 ? 1ull << htsz : (uint64_t)htsz; }
+static uint32_t ext_bucket_mul(uint32_t htsz) { return htsz <= 31 || !(htsz & (htsz - 1)) ? 0u : htsz; }      // the bucket function follows from the bucket COUNT alone: a power of two -> the mask
+static int ext_check_args(uint64_t w, uint32_t htsz, uint32_t layout)
+{
+    if (!w || w > (1ull << 36) || htsz < 1) return fail(BSGS_ERR_ARG, "need 0 < w <= 2^36 and htsz >= 1");
+    if (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "layout must be BSGS_TABLE_LINES64_LIST or BSGS_TABLE_LINES128_LIST");
+    if (ext_bucket_mul(htsz) && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "a bucket count that is not 2^htsz needs BSGS_TABLE_LINES128_LIST (only the 128-byte-line kernels carry the multiplicative bucket function)");
+    return BSGS_OK;
+}
 static int ext_check(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
 {
     if (!d) return fail(BSGS_ERR_ARG, "null");
-    if (!w || w > (1ull << 36) || htsz < 1 || htsz > 31) return fail(BSGS_ERR_ARG, "need 0 < w <= 2^36 and 1 <= htsz <= 31");
-    if (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "layout must be BSGS_TABLE_LINES64_LIST or BSGS_TABLE_LINES128_LIST");
-    return BSGS_OK;
+    return ext_check_args(w, htsz, layout);
 }
 
 // upper estimate of the entries that will not fit their line (Poisson loads), with slack
 static uint64_t ext_list_capacity(uint64_t w, uint32_t htsz, uint32_t layout)
 {
-    const unsigned cap_line = layout == BSGS_TABLE_LINES128_LIST ? 30 : 14;      // the last word of a full line is the bound of its overflow entries (ext_scatter_kernel)
-    const double buckets = (double)(1ull << htsz);
+    const unsigned cap_line = layout == BSGS_TABLE_LINES128_LIST ? 30 : 14;      // the last word of a full line is the bound of its overflow entries (OVERFLOW BOUND, support_kernels.hip.h)
+    const double buckets = (double)ext_buckets(htsz);
     return std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / buckets, cap_line, buckets)) + (1u << 20));
 }
 
 extern "C" int bsgs_ext_overflow_capacity(uint64_t w, uint32_t htsz, uint32_t layout, uint64_t *cap)
 {
-    if (!cap || !w || htsz < 1 || htsz > 31 || (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST)) return fail(BSGS_ERR_ARG, "bad args");
+    if (!cap) return fail(BSGS_ERR_ARG, "null");
+    const int rc = ext_check_args(w, htsz, layout);
+    if (rc) return rc;
     *cap = bsgs_ovf_slots(ext_list_capacity(w, htsz, layout));
     return BSGS_OK;
 }
@@ -291,7 +303,7 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
     DevBuf listb;
     HIPCHK(listb.alloc(ovf_cap * 8));
     u64 *ovf = listb.as<u64>();
-    const uint64_t ht_items = 1ull << htsz, line_bytes = 64ull << (lplog - 2);
+    const uint64_t ht_items = ext_buckets(htsz), line_bytes = 64ull << (lplog - 2);
     StageClock clk;
     size_t fr = 0, tot = 0;
     HIPCHK(bsgs_mem_available(&fr, &tot));
@@ -307,7 +319,7 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
         int rc = gen.init(d, w);
         if (rc) return rc;
         KeySink K{};
-        K.lines = (u32 *)lines; K.ovf = ovf; K.ovf_cap = ovf_cap; K.counters = cnt.as<unsigned long long>(); K.mask = (u32)(ht_items - 1);
+        K.lines = (u32 *)lines; K.ovf = ovf; K.ovf_cap = ovf_cap; K.counters = cnt.as<unsigned long long>(); K.mask = (u32)(ht_items - 1); K.mul = ext_bucket_mul(htsz);
         for (uint64_t first = 1; first <= w && rc == BSGS_OK; first += gen.chunk) {
             const uint64_t count = std::min<uint64_t>(gen.chunk, w - first + 1);
             rc = lplog == 2 ? gen.run<2>(first, count, K) : gen.run<3>(first, count, K);
@@ -331,9 +343,10 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
         DevBuf sorted, tmp;
         HIPCHK(sorted.alloc(h[1] * 8));
         size_t tmp_bytes = 0;
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, 32u + htsz, d->stream));
+        const unsigned key_bits = 32u + (htsz <= 31 ? htsz : 32u);          // (bucket << 32 | hash): the buckets of a non-power-of-two table need all 32 bits
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, key_bits, d->stream));
         HIPCHK(tmp.alloc(tmp_bytes));
-        HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, 32u + htsz, d->stream));
+        HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, key_bits, d->stream));
         HIPCHK(hipMemcpyAsync(ovf, sorted.p, h[1] * 8, hipMemcpyDeviceToDevice, d->stream));
         const int rblocks = (int)std::min<uint64_t>((h[1] + 255) / 256, 1u << 16);
         if (lplog == 2) hipLaunchKernelGGL(ext_refine_kernel<2>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1]);
@@ -369,7 +382,7 @@ extern "C" int bsgs_install_table_ext_device(bsgs_dev *d, const void *lines_dev,
     const bool mine = d->recv_lines && lines_dev == d->recv_lines && ovf_dev == d->recv_ovf;    // bsgs_alloc_table_ext_recv's buffers
     // (install_lines frees the previous TABLE, never the receive buffers; they change hands only once the install succeeded: a refused table
     // leaves them with bsgs_free_recv / bsgs_dev_close)
-    rc = bsgs_install_lines(d, (u32x4 *)lines_dev, layout == BSGS_TABLE_LINES128_LIST ? 3 : 2, (u64 *)ovf_dev, ovf_n, 1ull << htsz, w, overflow_buckets);
+    rc = bsgs_install_lines(d, (u32x4 *)lines_dev, layout == BSGS_TABLE_LINES128_LIST ? 3 : 2, (u64 *)ovf_dev, ovf_n, ext_buckets(htsz), w, overflow_buckets);
     if (rc) return rc;
     if (mine) { d->recv_lines = nullptr; d->recv_ovf = nullptr; }
     d->lines_owned = mine;                                            // otherwise borrowed: the caller keeps both buffers alive
@@ -390,7 +403,7 @@ extern "C" int bsgs_alloc_table_ext_recv(bsgs_dev *d, uint64_t w, uint32_t htsz,
     if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
     bsgs_free_table(d);
     bsgs_free_recv(d);
-    const uint64_t ht_items = 1ull << htsz, line_bytes = layout == BSGS_TABLE_LINES128_LIST ? 128 : 64;
+    const uint64_t ht_items = ext_buckets(htsz), line_bytes = layout == BSGS_TABLE_LINES128_LIST ? 128 : 64;
     uint64_t cap = 0;
     rc = bsgs_ext_overflow_capacity(w, htsz, layout, &cap);
     if (rc) return rc;
@@ -411,7 +424,7 @@ extern "C" int bsgs_build_baby_table_ext(bsgs_dev *d, uint64_t w, uint32_t htsz,
     HIPCHK(hipSetDevice(d->id));
     bsgs_free_table(d);
     const int lplog = layout == BSGS_TABLE_LINES128_LIST ? 3 : 2;
-    const uint64_t ht_items = 1ull << htsz, line_bytes = 64ull << (lplog - 2);
+    const uint64_t ht_items = ext_buckets(htsz), line_bytes = 64ull << (lplog - 2);
     uint64_t ovf_cap = 0;
     rc = bsgs_ext_overflow_capacity(w, htsz, layout, &ovf_cap);
     if (rc) return rc;

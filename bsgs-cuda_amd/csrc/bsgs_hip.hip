@@ -144,7 +144,7 @@ static void free_table(bsgs_dev *d)
     if (d->csr && d->csr_owned) (void)hipFree(d->csr);
     if (d->lines && d->lines_owned) (void)bsgs_big_free(d->lines);
     if (d->ovf && d->lines_owned) (void)hipFree(d->ovf);
-    d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true; d->auto_tpl = 0;
+    d->csr = nullptr; d->lines = nullptr; d->ovf = nullptr; d->ovf_n = 0; d->layout = 0; d->lines_owned = true; d->auto_tpl = 0; d->bucket_mul = 0;
     d->narrow_off = false;                  // memory was short for a narrow copy of the giants ONCE: another table, another try
 }
 void bsgs_free_table(bsgs_dev *d) { free_table(d); }
@@ -557,11 +557,14 @@ static int validate_ext_table(bsgs_dev *d, const u32x4 *lines, int lplog, const 
 int bsgs_install_lines(bsgs_dev *d, u32x4 *lines, int lplog, u64 *ovf, uint64_t ovf_n, uint64_t ht_items, uint64_t w,
                        uint64_t overflow_buckets)
 {
+    if (ht_items < 2 || ht_items >= (1ull << 32)) return fail(BSGS_ERR_ARG, "2 <= buckets < 2^32");
+    if ((ht_items & (ht_items - 1)) && lplog != 3) return fail(BSGS_ERR_ARG, "a bucket count that is not a power of two needs 128-byte lines");
     if (ovf) { int rc = validate_ext_table(d, lines, lplog, ovf, ovf_n, ht_items); if (rc) return rc; }
     free_table(d);
     d->lines = lines; d->lines_bytes = ht_items * (64ull << (lplog - 2));
     d->ovf = ovf; d->ovf_n = ovf_n;
     d->ht_items = ht_items; d->w = w; d->overflow = overflow_buckets;
+    d->bucket_mul = (ht_items & (ht_items - 1)) ? (uint32_t)ht_items : 0u;      // any number of buckets: the multiplicative bucket function (giant_kernel.hip.h bucket_of)
     d->layout = lplog == 3 ? BSGS_TABLE_LINES128 : BSGS_TABLE_LINES64;
     return BSGS_OK;
 }
@@ -723,7 +726,7 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     A.g2 = nb ? nb->g2 : d->g2; A.chain = d->chain; A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.hitbuf = d->hitbuf;
     A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.pparam = pi; A.T = Ti;
     A.max_hits = d->max_hits; A.tile_seq = seq; A.ntiles = ntiles;
-    A.debug_flags = d->debug_flags; A.pad0 = 0;
+    A.debug_flags = d->debug_flags; A.bucket_mul = d->bucket_mul;
     A.centres_dev = centres_dev;
     A.digest = d->digest ? d->digest + (uint64_t)seq * Ti * 2 : nullptr;
     A.chain_pad = d->chain_pad; A.chain_mode = 0;
@@ -1254,7 +1257,7 @@ extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
             free_table(d);
             return fail(rc, "%s", why.c_str());
         }
-        d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->lines_bytes = s->lines_bytes; d->layout = s->layout;
+        d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->lines_bytes = s->lines_bytes; d->layout = s->layout; d->bucket_mul = s->bucket_mul;
     }
     for (int i = 1; i < n; i++) {
         if (devs[i] == s) continue;
@@ -1333,6 +1336,63 @@ extern "C" int bsgs_table_checksum(bsgs_dev *d, uint64_t sums[4])
     for (int k = 0; k < 4; k++) sums[k] = h[k];
     return BSGS_OK;
 }
+// ---- structural verification of the installed table (the reference's checkHT / checkHTpack, 1_9_7File.pb:3599-3627, 3101-3134, 2797-2805) ----------------
+// out[0] entries held by bucket lines (or by the CSR image: over-full buckets of BSGS_TABLE_LINES64 / 128, everything of BSGS_TABLE_CSR), [1] over-full lines,
+// [2] keys in the overflow set, [3] duplicates (a line's last word that is also a key of the set), [4] malformed lines / buckets, [5] lines / buckets not ascending,
+// [6] w as installed, [7] out[0] + out[2] - out[3]: must equal [6].  One streaming pass (128 GiB of lines: 40 ms).
+extern "C" int bsgs_table_census(bsgs_dev *d, uint64_t out[8])
+{
+    if (!d || !out) return fail(BSGS_ERR_ARG, "null");
+    if (!d->layout) return fail(BSGS_ERR_STATE, "no table on device");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    HIPCHK(hipSetDevice(d->id));
+    unsigned long long *c = nullptr, h[6] = {0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMalloc(&c, sizeof h));
+    hipError_t e = hipMemsetAsync(c, 0, sizeof h, d->stream);
+    const int blocks = (int)std::min<uint64_t>((d->ht_items + 255) / 256, (uint64_t)d->prop.multiProcessorCount * 32);
+    if (d->lines) {
+        if (d->layout == BSGS_TABLE_LINES128) hipLaunchKernelGGL(table_census_kernel<3>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)d->lines, d->ht_items, (const u32 *)d->csr, (const u64 *)d->ovf, d->ovf_n, c);
+        else                                  hipLaunchKernelGGL(table_census_kernel<2>, dim3(blocks), dim3(256), 0, d->stream, (const u32x4 *)d->lines, d->ht_items, (const u32 *)d->csr, (const u64 *)d->ovf, d->ovf_n, c);
+        if (d->ovf) hipLaunchKernelGGL(set_census_kernel, dim3((int)std::min<uint64_t>((d->ovf_n + 255) / 256, (uint64_t)d->prop.multiProcessorCount * 32)), dim3(256), 0, d->stream, (const u64 *)d->ovf, d->ovf_n, c);
+    } else hipLaunchKernelGGL(csr_census_kernel, dim3(blocks), dim3(256), 0, d->stream, (const u32 *)d->csr, d->ht_items, c);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, c, sizeof h, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void)hipFree(c);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "table census: %s", hipGetErrorString(e));
+    for (int k = 0; k < 6; k++) out[k] = h[k];
+    out[6] = d->w; out[7] = h[0] + h[2] - h[3];
+    return BSGS_OK;
+}
+
+// Batched membership through the shipped probe: found[i] = 1 when the tile kernel would report a hit for the 64-bit key keys64[i] (low 64 bits of an x coordinate:
+// bucket from the low word, hash = the high word).  Host buffers; n keys, n bytes.
+extern "C" int bsgs_table_lookup(bsgs_dev *d, const uint64_t *keys64, uint64_t n, uint8_t *found)
+{
+    if (!d || !keys64 || !found) return fail(BSGS_ERR_ARG, "null");
+    if (!d->layout) return fail(BSGS_ERR_STATE, "no table on device");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued: collect them first");
+    if (!n) return BSGS_OK;
+    if (n > (1ull << 31)) return fail(BSGS_ERR_ARG, "at most 2^31 keys per call");
+    HIPCHK(hipSetDevice(d->id));
+    u64 *dk = nullptr; unsigned char *df = nullptr;
+    HIPCHK(hipMalloc(&dk, n * 8));
+    if (hipMalloc(&df, n) != hipSuccess) { (void)hipFree(dk); return fail(BSGS_ERR_NOMEM, "lookup buffers"); }
+    TileArgs A = {};
+    A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.bucket_mul = d->bucket_mul;
+    hipError_t e = hipMemcpyAsync(dk, keys64, n * 8, hipMemcpyHostToDevice, d->stream);
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    if (d->layout == BSGS_TABLE_LINES64)       hipLaunchKernelGGL(table_lookup_kernel<2>, grid, block, 4096, d->stream, A, (const u64 *)dk, (u64)n, df);
+    else if (d->layout == BSGS_TABLE_LINES128) hipLaunchKernelGGL(table_lookup_kernel<3>, grid, block, 8192, d->stream, A, (const u64 *)dk, (u64)n, df);
+    else                                       hipLaunchKernelGGL(table_lookup_kernel<0>, grid, block, 0, d->stream, A, (const u64 *)dk, (u64)n, df);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(found, df, n, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    (void)hipFree(dk); (void)hipFree(df);
+    if (e != hipSuccess) return fail(BSGS_ERR_HIP, "table lookup: %s", hipGetErrorString(e));
+    return BSGS_OK;
+}
+
 // test hook: flip bits of ONE byte of the installed table (bucket lines if the layout has them, else the CSR image) -- the corrupted replica
 // the verification must catch (tests/test_gpu_round4.py, bench.py BENCH_CORRUPT_RANK)
 extern "C" int bsgs_debug_corrupt_table(bsgs_dev *d, uint64_t byte_offset, uint32_t xor_mask)

@@ -60,6 +60,7 @@ struct bsgs_dev {
     u64 *ovf = nullptr;         // "lines + overflow list" formats (no CSR on the device): hash set of (bucket << 32 | hash)
     uint64_t ovf_n = 0;         // slots (power of two)
     uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
+    uint32_t bucket_mul = 0;    // 0: ht_items is a power of two, bucket = x & (ht_items - 1); else = ht_items: bucket = floor(xlo * ht_items / 2^32) (extended tables, 128-byte lines)
     uint32_t layout = 0;        // probe layout: 1 csr, 2 lines64, 3 lines128 (ovf != NULL: reported as 4 / 5)
     u32 *hitbuf = nullptr;      // device
     u32 *hit_host = nullptr;    // pinned mirror

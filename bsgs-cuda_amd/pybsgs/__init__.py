@@ -26,6 +26,7 @@ NATIVE_SYMBOLS = [
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_quirk_count", "bsgs_broadcast_tables",
     "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_chain_grades", "bsgs_debug_grade_rule", "bsgs_debug_xcd_profile",
     "bsgs_table_checksum", "bsgs_debug_corrupt_table", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
+    "bsgs_table_census", "bsgs_table_lookup",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -122,6 +123,8 @@ def lib():
             "bsgs_alloc_table_ext_recv": [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)],
             "bsgs_debug_last_kernel": [vp, C.c_char_p, C.c_int],
             "bsgs_table_checksum": [vp, C.POINTER(C.c_uint64)],
+            "bsgs_table_census": [vp, C.POINTER(C.c_uint64)],
+            "bsgs_table_lookup": [vp, vp, C.c_uint64, vp],
             "bsgs_debug_corrupt_table": [vp, C.c_uint64, C.c_uint32],
             "bsgs_debug_table_owner": [vp, C.POINTER(C.c_int)],
             "bsgs_prepare": [vp],
@@ -281,6 +284,26 @@ class Device:
         s = (C.c_uint64 * 4)()
         _chk(self.L.bsgs_table_checksum(self.h, s))
         return [int(x) for x in s]
+
+    def table_census(self):
+        """one streaming pass over the installed table (the reference's checkHT / checkHTpack, 1_9_7File.pb:3599-3627, 3101-3134): what it holds, and whether
+        entries in lines + keys in the overflow set - duplicates equals w"""
+        c = (C.c_uint64 * 8)()
+        _chk(self.L.bsgs_table_census(self.h, c))
+        names = ("line_entries", "overfull_lines", "set_keys", "duplicates", "malformed_lines", "unsorted_lines", "w", "total")
+        return dict(zip(names, (int(x) for x in c)))
+
+    def table_lookup(self, keys64):
+        """batched membership through the shipped probe: keys64 = iterable of 64-bit keys (low 64 bits of x) -> list of bool"""
+        import array
+        a = array.array("Q", keys64)
+        n = len(a)
+        if not n:
+            return []
+        out = (C.c_uint8 * n)()
+        addr, _ = a.buffer_info()
+        _chk(self.L.bsgs_table_lookup(self.h, C.c_void_p(addr), n, C.cast(out, C.c_void_p)))
+        return [bool(x) for x in out]
 
     def debug_corrupt_table(self, byte_offset, xor_mask=1):
         """test hook: flip bits of one byte of the installed table (what replica verification must catch)"""

@@ -103,6 +103,7 @@ def lib():
             "o_fast_tile_slice_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, u8p, C.c_uint64, C.c_int,
                                                C.POINTER(C.c_uint64)]),
             "o_fast_tile_slice_keys_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, u8p]),
+            "o_fast_keys_of_scalars_mt": (C.c_int, [u8p, C.c_uint64, u8p, C.c_int]),
             "o_tile_xs": (C.c_int, [ppt, ppt, C.c_uint32, pfe, pfe, pfe]),
             "o_job_init": (C.c_int, [C.POINTER(Job), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.c_uint32, pfe, ppt, pfe]),
@@ -253,3 +254,16 @@ def fast_tile_slice(P, g2buf, t, b, p, htbuf, htsz, tid0, tid1, nthreads=1):
     lib().o_fast_tile_slice_mt(C.byref(Pt.from_ints(*P)), plain.ctypes.data_as(C.c_void_p), tid0 * p, p, tid0, tid1, ptr(htbuf),
                                1 << htsz, nthreads, out)
     return int(out[0]), int(out[1]), int(out[2]), time.time() - t0
+
+
+def fast_keys_of_scalars(scalars, nthreads=None):
+    """low 64 bits of x(k*G) for every 64-bit scalar k (numpy uint64 array out): the expected keys of a sampled-membership check of a GPU-built
+    baby table (the reference's checkHT / checkHTpack, 1_9_7File.pb:3599-3627, 3101-3134); oracle/cpu_fast.c on host threads"""
+    import os
+    import numpy as np
+    k = np.ascontiguousarray(np.asarray(scalars, dtype=np.uint64))
+    out = np.zeros(len(k), dtype=np.uint64)
+    if len(k):
+        rc = lib().o_fast_keys_of_scalars_mt(k.ctypes.data_as(C.c_void_p), len(k), out.ctypes.data_as(C.c_void_p), nthreads or min(64, os.cpu_count() or 1))
+        assert rc == 0
+    return out

@@ -75,6 +75,72 @@ def test_fullsize_planted_and_layout_agreement(wexp, htsz):
     dev.close()
 
 
+def verify_table(dev, w, n_in=100000, n_out=100000, seed=1, extra_k=()):
+    """The reference verifies every table it builds or loads (checkHT / checkHTpack: sampled "every k*G is found", 1_9_7File.pb:3599-3627, 3101-3134;
+    ascending buckets, 1_9_7File.pb:2797-2805).  Same here, for any layout and size: (1) the census -- one streaming pass over what the device holds:
+    entries in lines + keys in the overflow set - duplicates must equal w, no malformed line; (2) batched membership through the SHIPPED probe:
+    n_in random k in [1, w] (with k = 1, w, the 32-bit boundaries of the reference format) must ALL be found, n_out random k in (w, 5w] must all miss
+    except by a 32-bit hash collision (probability load / 2^32 each).  Expected keys: oracle/cpu_fast.c on host threads, pinned to the literal port
+    (tests/test_oracle_kat.py).  Returns (census, seconds spent in census + lookups)."""
+    import time
+    import numpy as np
+    import oracle_lib as O
+    rng = np.random.default_rng(seed)
+    special = [k for k in (1, 2, w, w - 1, w // 2, 1 << 32, (1 << 32) - 1, (1 << 32) + 1, 1 << 33, (1 << 33) + 1) + tuple(extra_k) if 1 <= k <= w]
+    k_in = np.concatenate([np.array(special, dtype=np.uint64), rng.integers(1, w + 1, size=n_in, dtype=np.uint64)])
+    k_out = rng.integers(w + 1, 5 * w + 1, size=n_out, dtype=np.uint64)
+    keys_in, keys_out = O.fast_keys_of_scalars(k_in), O.fast_keys_of_scalars(k_out)
+    t0 = time.time()
+    c = dev.table_census()
+    found_in = dev.table_lookup(keys_in.tolist())
+    found_out = dev.table_lookup(keys_out.tolist())
+    dt = time.time() - t0
+    assert c["w"] == w and c["total"] == w, c
+    assert c["malformed_lines"] == 0, c
+    missing = [int(k) for k, f in zip(k_in, found_in) if not f]
+    assert not missing, ("baby points missing from the table", missing[:10], len(missing))
+    fp = sum(found_out)
+    return c, dt, fp
+
+
+def test_census_and_sampled_membership_of_small_tables_in_every_layout():
+    """census + membership (verify_table) on small tables in every device layout: the three made from a reference-format image (with and without resident
+    CSR), the CSR image alone, direct-built 64- and 128-byte lines with heavy overflow, and direct-built tables with a bucket count that is NOT a power
+    of two (bucket = floor(xlo * M / 2^32)); then a corrupted line header must show in the census."""
+    import pybsgs
+    dev = pybsgs.Device(0)
+    wexp, htsz = 20, 17                                    # load 8
+    w = 1 << wexp
+    img = torch.empty((1 << htsz) + 1 + w, dtype=torch.int32, device="cuda:0")
+    dev.build_baby_tables_device(w, htsz, img.data_ptr())
+    for layout in (pybsgs.TABLE_CSR, pybsgs.TABLE_LINES64, pybsgs.TABLE_LINES128, pybsgs.TABLE_LINES64_LIST, pybsgs.TABLE_LINES128_LIST):
+        dev.upload_htgpu_device(img.data_ptr(), 1 << htsz, w, layout)
+        c, _, fp = verify_table(dev, w, 20000, 20000, seed=layout)
+        assert c["unsorted_lines"] == 0, (layout, c)       # the reference's files have ascending buckets, and so have the lines made from them
+        assert fp <= 2, (layout, fp)                       # 2e4 * 8 / 2^32
+    del img
+    for w2, hb, layout in ((1 << 22, 18, pybsgs.TABLE_LINES64_LIST),          # load 16: most 64-byte lines over-full
+                           (1 << 22, 18, pybsgs.TABLE_LINES128_LIST),
+                           (1 << 22, 150001, pybsgs.TABLE_LINES128_LIST),      # 150001 buckets (not a power of two), load 28: many 128-byte lines over-full
+                           (3 * (1 << 20) + 12345, 3 * (1 << 17), pybsgs.TABLE_LINES128_LIST),   # 1.5 * 2^18 buckets, load 8: -w 35's shape in small
+                           (1000003, 48611, pybsgs.TABLE_LINES128_LIST)):
+        dev.build_baby_table_ext(w2, hb, layout)
+        buckets = hb if hb > 31 else 1 << hb
+        lay, nbytes, over = dev.table_info()
+        assert lay == layout and nbytes >= buckets * (64 if layout == pybsgs.TABLE_LINES64_LIST else 128)
+        c, _, fp = verify_table(dev, w2, 20000, 20000, seed=hb)
+        assert c["overfull_lines"] == over, (c, over)
+        assert fp <= 3
+    # a damaged table is seen: one bit of a line header (entry count 8 -> 9: a word of padding becomes an "entry")
+    c0 = dev.table_census()
+    dev.debug_corrupt_table(128 * 7, 1)
+    c1 = dev.table_census()
+    assert c1["total"] != c0["total"] or c1["malformed_lines"] > 0, (c0, c1)
+    with pytest.raises(pybsgs.BsgsError):
+        dev.build_baby_table_ext(1 << 20, 48611, pybsgs.TABLE_LINES64_LIST)      # a bucket count that is not a power of two needs 128-byte lines
+    dev.close()
+
+
 def test_extended_table_w34():
     """BASELINE configs 3/5 geometry: -w 34 -htsz 31 (2^34 baby points, 128 GiB of bucket lines + overflow list), built on
     the GPU by bsgs_build_baby_table_ext.  No reference format exists at this size (1_9_7File.pb:4412-4418 caps w below
@@ -114,6 +180,12 @@ def test_extended_table_w34():
         assert set(expect) <= set(mine), (k, expect, mine)
         extra += len(mine) - len(expect)
     assert extra <= 4
+    # the table itself, pinned the way the reference pins its own: census (lines + set - duplicates = 2^34) and 2 x 10^5 sampled
+    # keys through the shipped probe, in well under 10 s
+    c, dt, fp = verify_table(dev, w, 100000, 100000, seed=34)
+    assert c["overfull_lines"] == ovf and c["set_keys"] > 0 and c["duplicates"] > 0, c
+    assert fp <= 3 and dt < 10.0, (fp, dt)
+    print("census -w 34:", c, "census + 2e5 lookups: %.2f s" % dt)
     dev.close()
 
 

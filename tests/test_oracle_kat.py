@@ -107,3 +107,27 @@ def test_fast_cpu_keys_equal_the_literal_port():
         a = O.tile_slice_keys(P, g2, t, b, p, 0, t * b)
         f = O.fast_tile_slice_keys(P, g2, t, b, p, 0, t * b, 4)
         assert a.shape == f.shape == (t * b, p, 2) and (a == f).all()
+
+
+def test_fast_cpu_keys_of_scalars_equal_the_literal_port_and_the_table_builder():
+    """o_fast_keys_of_scalars_mt (the expected keys of the GPU tests' sampled-membership check: low 64 bits of x(k*G), Jacobian additions over a table
+    of 2^j*G, batched inversion, host threads) against the literal port's scalar multiplication (o_PTMULX64, Curve64.pb LSB-first double-and-add) and
+    against the keys the oracle's table builder files under (o_build_baby_tables: bucket = x & mask, hash = bits 32..63)"""
+    import random
+    import numpy as np
+    import oracle_lib as O
+    rnd = random.Random(77)
+    ks = [1, 2, 3, 255, 256, 2**32 - 1, 2**32, 2**32 + 1, 2**33, 2**34, 2**36 - 1, 2**63 + 12345, 2**64 - 1] + [rnd.getrandbits(rnd.randint(1, 64)) or 1 for _ in range(120)]
+    got = O.fast_keys_of_scalars(ks, nthreads=3)
+    for k, g in zip(ks, got):
+        assert O.pt_mul(k)[0] & (2**64 - 1) == int(g), k
+    # block boundaries of the batched inversion (256 keys per block) and of the thread split
+    ks2 = list(range(1, 1200))
+    assert [int(v) for v in O.fast_keys_of_scalars(ks2, nthreads=4)] == [int(v) for v in O.fast_keys_of_scalars(ks2, nthreads=1)]
+    w, htsz = 1024, 8
+    htgpu, _ = O.build_baby_tables(w, htsz)
+    img = np.frombuffer(htgpu, dtype=np.uint32)
+    starts, items = img[: (1 << htsz) + 1], img[(1 << htsz) + 1:]
+    for k, key in zip(ks2[:w], O.fast_keys_of_scalars(ks2[:w])):
+        b, h = int(key) & ((1 << htsz) - 1), int(key) >> 32
+        assert h in items[starts[b]:starts[b + 1]].tolist(), k
