@@ -30,7 +30,9 @@
 struct KeySink {
     u64 *keys; u32 *pos; u32 pos_base;  // SINK 0: sort key (bucket << 32 | hash) and position of point number idx (197:2561, 2583, 1221)
     u32 *lines; u64 *ovf; u64 ovf_cap; unsigned long long *counters; u32 mask;      // SINK 2 / 3: the line of bucket b counts its arrivals in word 0
-    u32 mul;                            // 0: bucket = x & mask ; M: bucket = floor(xlo * M / 2^32) (any number of buckets: giant_kernel.hip.h bucket_of)
+    u32 mul;                            // 0: bucket = x & mask ; M: any number of buckets, bucket from 48 bits of the key (giant_kernel.hip.h bucket_mul48)
+    u32 b_lo, b_hi;                     // SINK 2 / 3: only buckets [b_lo, b_hi) are filed, in lines[(bucket - b_lo) * WORDS] (a SLICE of the table: one engine of N builds 1/N of the
+                                        // lines -- every engine generates every point -- and an all-gather completes them; the whole table: 0, number of buckets)
 };
 template <int SINK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) baby_keys_kernel(const u32x4 *__restrict__ helper, const u32x4 *__restrict__ bases, const KeySink K,
@@ -55,9 +57,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (idx >= count) return;
         if (SINK == 0) { K.keys[idx] = ((u64)((u32)key & K.mask) << 32) | (key >> 32); K.pos[idx] = K.pos_base + (u32)idx; return; }
         settle();
-        pend_bucket = K.mul ? __umulhi((u32)key, K.mul) : ((u32)key & K.mask);
+        const u32 bucket = K.mul ? bucket_mul48((u32)key, (u32)(key >> 32), K.mul) : ((u32)key & K.mask);
+        if (bucket < K.b_lo || bucket >= K.b_hi) return;                       // another engine's slice
+        pend_bucket = bucket;
         pend_hash = (u32)(key >> 32);
-        pend_line = K.lines + pend_bucket * WORDS;
+        pend_line = K.lines + (u64)(bucket - K.b_lo) * WORDS;
         pend_slot = atomicAdd(pend_line, 1u);
     };
     fe Sx, Sy;
@@ -185,6 +189,15 @@ struct KeyGen {
         HIPCHK(hipMemcpy(gtab.p, tab.data(), tab.size(), hipMemcpyHostToDevice));
         return BSGS_OK;
     }
+    // after the last run() and a stream synchronisation: did the device walk produce every base point?  (an infinity among the bases (first + tid)*G would be
+    // filed as a dummy point; unreachable for k < 2^36 < n, but never silently)
+    int check()
+    {
+        uint32_t bad = 0;
+        HIPCHK(hipMemcpy(&bad, status.p, 4, hipMemcpyDeviceToHost));
+        if (bad) return fail(BSGS_ERR_DEGENERATE, "table build: %u base point(s) of the generator are the point at infinity", bad);
+        return BSGS_OK;
+    }
     // queue the generation of points first .. first + count - 1 (count <= chunk) into the sink; asynchronous
     template <int SINK>
     int run(uint64_t first, uint64_t count, const KeySink &K)
@@ -208,6 +221,12 @@ static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img,
     const uint64_t ht_items = 1ull << htsz;
     StageClock clk;
     DevBuf sk, sk2, pos, pos2, tmp, offs;
+    {   // keys + positions twice over (the sort's output) + the generator's scratch: say so instead of failing half-way
+        size_t fr = 0, tot = 0;
+        HIPCHK(bsgs_mem_available(&fr, &tot));
+        const uint64_t need = 24 * w + KeyGen::scratch_bytes(w) + (64ull << 20);
+        if (need > fr) return fail(BSGS_ERR_NOMEM, "table build needs %.1f GiB of device memory, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
+    }
     HIPCHK(sk.alloc(w * 8)); HIPCHK(pos.alloc(w * 4));
     {
         KeyGen gen;
@@ -221,6 +240,8 @@ static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img,
             if (rc) return rc;
         }
         HIPCHK(hipStreamSynchronize(d->stream));                 // the generator's scratch goes out of scope here
+        rc = gen.check();
+        if (rc) return rc;
         clk.lap(d, "generate the points (keys)");
     }
     // sort by (bucket, hash), positions ride along (stable: entries with an identical (bucket, hash) pair stay in ascending position order)
@@ -263,7 +284,7 @@ static double expected_overflow_entries(double lambda, unsigned cap, double buck
 }
 
 // `htsz` of the extended-table entry points: 1..31 = 2^htsz buckets (bucket = x & mask, like the reference's tables); a value above 31 IS the number of
-// buckets (any number below 2^32, 128-byte lines: bucket = floor(xlo * buckets / 2^32)) -- what lets a table fill the HBM there is (include/bsgs_hip.h)
+// buckets (any number below 2^32, 128-byte lines: the bucket comes from 48 bits of the key, giant_kernel.hip.h bucket_mul48) -- what lets a table fill the HBM there is (include/bsgs_hip.h)
 static uint64_t ext_buckets(uint32_t htsz) { return htsz <= 31 ? 1ull << htsz : (uint64_t)htsz; }
 static uint32_t ext_bucket_mul(uint32_t htsz) { return htsz <= 31 || !(htsz & (htsz - 1)) ? 0u : htsz; }      // the bucket function follows from the bucket COUNT alone: a power of two -> the mask
 static int ext_check_args(uint64_t w, uint32_t htsz, uint32_t layout)
@@ -296,21 +317,23 @@ extern "C" int bsgs_ext_overflow_capacity(uint64_t w, uint32_t htsz, uint32_t la
     return BSGS_OK;
 }
 
-// the builder proper: lines = 2^htsz lines, ovf_table = ovf_slots u64 (both device memory)
-static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32x4 *lines, u64 *ovf_table, uint64_t ovf_slots, uint64_t *ovf_n, uint64_t *overflow_buckets)
+// the builder proper, for the buckets [b_lo, b_hi) of the table (the whole table: 0, number of buckets): `lines` = the lines of THOSE buckets (b_hi - b_lo lines, device
+// memory), list = room for list_cap overflow entries.  On return the lines are closed and refined and list[0 .. *n_list) holds the overflow entries (bucket << 32 | hash,
+// global bucket numbers), sorted; *overflow_buckets = over-full lines of the slice.  The caller makes the hash set (bsgs_ovf_fill) -- of one list, or of the lists of all slices.
+static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32x4 *lines, uint64_t b_lo, uint64_t b_hi, u64 *list, uint64_t list_cap, uint64_t *n_list,
+                           uint64_t *overflow_buckets)
 {
-    const uint64_t ovf_cap = ovf_slots / 2;                           // the hash set takes at most that many keys
-    DevBuf listb;
-    HIPCHK(listb.alloc(ovf_cap * 8));
-    u64 *ovf = listb.as<u64>();
-    const uint64_t ht_items = ext_buckets(htsz), line_bytes = 64ull << (lplog - 2);
+    u64 *ovf = list;
+    const uint64_t ovf_cap = list_cap;
+    const uint64_t ht_items = ext_buckets(htsz), line_bytes = 64ull << (lplog - 2), nlines = b_hi - b_lo;
+    if (b_lo >= b_hi || b_hi > ht_items) return fail(BSGS_ERR_ARG, "bucket range [%llu, %llu) of %llu", (unsigned long long)b_lo, (unsigned long long)b_hi, (unsigned long long)ht_items);
     StageClock clk;
     size_t fr = 0, tot = 0;
     HIPCHK(bsgs_mem_available(&fr, &tot));
     const uint64_t need = KeyGen::scratch_bytes(w) + (64ull << 20);
     if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table build needs %.1f GiB of scratch, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
     DevBuf cnt;
-    HIPCHK(hipMemsetAsync(lines, 0, ht_items * line_bytes, d->stream));
+    HIPCHK(hipMemsetAsync(lines, 0, nlines * line_bytes, d->stream));
     HIPCHK(cnt.alloc(16));
     HIPCHK(hipMemsetAsync(cnt.p, 0, 16, d->stream));
     clk.lap(d, "clear the bucket lines");
@@ -320,17 +343,20 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
         if (rc) return rc;
         KeySink K{};
         K.lines = (u32 *)lines; K.ovf = ovf; K.ovf_cap = ovf_cap; K.counters = cnt.as<unsigned long long>(); K.mask = (u32)(ht_items - 1); K.mul = ext_bucket_mul(htsz);
+        K.b_lo = (u32)b_lo; K.b_hi = (u32)std::min<uint64_t>(b_hi, 0xFFFFFFFFull);
         for (uint64_t first = 1; first <= w && rc == BSGS_OK; first += gen.chunk) {
             const uint64_t count = std::min<uint64_t>(gen.chunk, w - first + 1);
             rc = lplog == 2 ? gen.run<2>(first, count, K) : gen.run<3>(first, count, K);
         }
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(d->stream));                 // the generator's scratch goes out of scope here
+        rc = gen.check();
+        if (rc) return rc;
         clk.lap(d, "generate + scatter the points");
     }
-    const int fblocks = (int)std::min<uint64_t>(((ht_items << lplog) + 255) / 256, (uint64_t)d->prop.multiProcessorCount * 32);
-    if (lplog == 2) hipLaunchKernelGGL(ext_finalize_kernel<2>, dim3(fblocks), dim3(256), 0, d->stream, lines, ht_items, cnt.as<unsigned long long>());
-    else            hipLaunchKernelGGL(ext_finalize_kernel<3>, dim3(fblocks), dim3(256), 0, d->stream, lines, ht_items, cnt.as<unsigned long long>());
+    const int fblocks = (int)std::min<uint64_t>((nlines + 255) / 256, (uint64_t)d->prop.multiProcessorCount * 32);
+    if (lplog == 2) hipLaunchKernelGGL(ext_finalize_kernel<2>, dim3(fblocks), dim3(256), 0, d->stream, lines, nlines, cnt.as<unsigned long long>());
+    else            hipLaunchKernelGGL(ext_finalize_kernel<3>, dim3(fblocks), dim3(256), 0, d->stream, lines, nlines, cnt.as<unsigned long long>());
     HIPCHK(hipGetLastError());
     unsigned long long h[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, d->stream));
@@ -349,16 +375,52 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
         HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, key_bits, d->stream));
         HIPCHK(hipMemcpyAsync(ovf, sorted.p, h[1] * 8, hipMemcpyDeviceToDevice, d->stream));
         const int rblocks = (int)std::min<uint64_t>((h[1] + 255) / 256, 1u << 16);
-        if (lplog == 2) hipLaunchKernelGGL(ext_refine_kernel<2>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1]);
-        else            hipLaunchKernelGGL(ext_refine_kernel<3>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1]);
+        if (lplog == 2) hipLaunchKernelGGL(ext_refine_kernel<2>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1], (u64)b_lo);
+        else            hipLaunchKernelGGL(ext_refine_kernel<3>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1], (u64)b_lo);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(d->stream));
     }
-    int rc = bsgs_ovf_fill(d, ovf, h[1], ovf_table, ovf_slots);
-    if (rc) return rc;
-    clk.lap(d, "overflow list: sort, refine, set");
-    *ovf_n = ovf_slots; *overflow_buckets = h[0];
+    clk.lap(d, "overflow list: sort, refine");
+    *n_list = h[1]; *overflow_buckets = h[0];
     return BSGS_OK;
+}
+
+// the whole table: lines = all lines, ovf_table = ovf_slots u64 for the hash set (both device memory)
+static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32x4 *lines, u64 *ovf_table, uint64_t ovf_slots, uint64_t *ovf_n, uint64_t *overflow_buckets)
+{
+    const uint64_t ovf_cap = ovf_slots / 2;                           // the hash set takes at most that many keys
+    DevBuf listb;
+    HIPCHK(listb.alloc(ovf_cap * 8));
+    uint64_t n_list = 0;
+    int rc = ext_build_lines(d, w, htsz, lplog, lines, 0, ext_buckets(htsz), listb.as<u64>(), ovf_cap, &n_list, overflow_buckets);
+    if (rc) return rc;
+    rc = bsgs_ovf_fill(d, listb.as<u64>(), n_list, ovf_table, ovf_slots);
+    if (rc) return rc;
+    *ovf_n = ovf_slots;
+    return BSGS_OK;
+}
+
+// One SLICE of an extended table, for the "1/N each + all-gather" start-up of N engines (include/bsgs_hip.h): the lines of the buckets
+// [part * M / nparts, (part + 1) * M / nparts) are built IN PLACE inside the full line buffer `lines_dev`, the slice's overflow entries go to list_dev.
+extern "C" int bsgs_build_baby_table_ext_slice(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout, void *lines_dev, uint32_t part, uint32_t nparts, void *list_dev,
+                                               uint64_t list_cap, uint64_t *n_list, uint64_t *overflow_buckets)
+{
+    int rc = ext_check(d, w, htsz, layout);
+    if (rc) return rc;
+    if (!lines_dev || !list_dev || !n_list || !overflow_buckets) return fail(BSGS_ERR_ARG, "null");
+    const uint64_t M = ext_buckets(htsz);
+    if (!nparts || part >= nparts || M % nparts) return fail(BSGS_ERR_ARG, "part %u of %u: the %llu buckets must divide evenly", part, nparts, (unsigned long long)M);
+    HIPCHK(hipSetDevice(d->id));
+    const int lplog = layout == BSGS_TABLE_LINES128_LIST ? 3 : 2;
+    const uint64_t per = M / nparts, b_lo = per * part;
+    return ext_build_lines(d, w, htsz, lplog, (u32x4 *)lines_dev + (b_lo << lplog), b_lo, b_lo + per, (u64 *)list_dev, list_cap, n_list, overflow_buckets);
+}
+// the overflow hash set of an extended table from its overflow entries (one list, or the concatenated lists of all slices): set_dev = `slots` u64 (bsgs_ext_overflow_capacity)
+extern "C" int bsgs_build_overflow_set(bsgs_dev *d, const void *list_dev, uint64_t n, void *set_dev, uint64_t slots)
+{
+    if (!d || !set_dev || (n && !list_dev)) return fail(BSGS_ERR_ARG, "null");
+    HIPCHK(hipSetDevice(d->id));
+    return bsgs_ovf_fill(d, (const u64 *)list_dev, n, (u64 *)set_dev, slots);
 }
 
 extern "C" int bsgs_build_baby_table_ext_device(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout, void *lines_dev, void *ovf_dev,

@@ -1199,72 +1199,75 @@ extern "C" int bsgs_debug_xcd_profile(bsgs_dev *d, uint64_t first_tile, uint32_t
 }
 
 // ---- replicas for several GPUs of one process: the reference uploads G2 and htGPU to every GPU over PCIe (1_9_7File.pb:2337,
-// 2350, 4769-4843).  Here devs[0] holds the giants and the table (file-backed or GPU-built) and every other device gets its
-// replica by a direct device-to-device copy, all destinations at once, each on its own stream: on the fully connected xGMI mesh
-// of an MI355X node every destination has its own link to the source, so N-1 concurrent peer copies ARE the one-to-all schedule
-// (multi-process hosts broadcast with RCCL instead: bench.py / pybsgs.dist).
-extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
+// 2350, 4769-4843).  Here devs[0] holds the giants and the table (file-backed or GPU-built) and every other engine gets its replica over
+// xGMI: RCCL (one communicator per engine in this process, ncclBroadcast inside one group -- north_star's "RCCL over xGMI only to broadcast
+// htGPU at startup") when the engines sit on distinct GPUs, else -- one GPU listed twice, no librccl -- direct peer copies, all destinations
+// at once, each on its own stream (startup.hip: bsgs_fabric).  what: bit 0 = the giants, bit 1 = the table.
+extern "C" int bsgs_broadcast_tables_ex(bsgs_dev *const *devs, int n, uint32_t transport, uint32_t what, uint32_t *transport_used, double *seconds)
 {
     if (!devs || n < 1 || !devs[0]) return fail(BSGS_ERR_ARG, "null");
+    if (!(what & 3u)) return fail(BSGS_ERR_ARG, "nothing to replicate (what = 1 giants | 2 table)");
     bsgs_dev *s = devs[0];
-    if (!s->g2 || !s->layout) return fail(BSGS_ERR_STATE, "devs[0] must hold the giants and the table");
+    if ((what & 1u) && !s->g2) return fail(BSGS_ERR_STATE, "devs[0] must hold the giants");
+    if ((what & 2u) && !s->layout) return fail(BSGS_ERR_STATE, "devs[0] must hold the table");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 1; i < n; i++) {
+        if (!devs[i]) return fail(BSGS_ERR_ARG, "null device %d", i);
+        if (devs[i] == s) return fail(BSGS_ERR_ARG, "device %d is devs[0] itself", i);
+    }
+    bsgs_fabric *F = nullptr;
+    int rc = bsgs_fabric_open(&F, devs, n, transport);
+    if (rc) return rc;
+    if (transport_used) *transport_used = bsgs_fabric_is_rccl(F) ? BSGS_TRANSPORT_RCCL : BSGS_TRANSPORT_PEER;
+    // allocations first (every replica's buffers), then the transfers; a replica's table state (layout, sizes) is set only after every allocation and
+    // copy for it succeeded: a failure half-way leaves a device WITHOUT a table (bsgs_enqueue then refuses), never one with a layout and null pointers
+    std::vector<void *> g2(n, nullptr), csr(n, nullptr), lines(n, nullptr), ovf(n, nullptr);
+    g2[0] = s->g2; csr[0] = s->csr; lines[0] = s->lines; ovf[0] = s->ovf;
+    auto fail_all = [&](int code) {
+        const std::string why = bsgs_last_error();
+        for (int k = 1; k < n; k++) { (void)hipSetDevice(devs[k]->id); (void)hipStreamSynchronize(devs[k]->stream); if (what & 2u) { devs[k]->lines_owned = true; devs[k]->csr_owned = true; free_table(devs[k]); } }
+        bsgs_fabric_close(F);
+        return fail(code, "%s", why.c_str());
+    };
     for (int i = 1; i < n; i++) {
         bsgs_dev *d = devs[i];
-        if (!d) return fail(BSGS_ERR_ARG, "null device %d", i);
-        if (d == s) continue;
-        HIPCHK(hipSetDevice(d->id));
-        if (d->id != s->id) {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, d->id, s->id) == hipSuccess && can) {
-                hipError_t pe = hipDeviceEnablePeerAccess(s->id, 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(BSGS_ERR_HIP, "peer access %d -> %d: %s", d->id, s->id, hipGetErrorString(pe));
-                (void)hipGetLastError();
+        auto prepare = [&]() -> int {
+            HIPCHK(hipSetDevice(d->id));
+            if (what & 1u) {
+                int r = set_geometry(d, s->t, s->b, s->p);
+                if (r) return r;
+                if (d->Ti != s->Ti || d->pi != s->pi) return fail(BSGS_ERR_STATE, "device %d chose another batching", i);
+                g2[i] = d->g2;
             }
-        }
-        int rc = set_geometry(d, s->t, s->b, s->p);
-        if (rc) return rc;
-        if (d->Ti != s->Ti || d->pi != s->pi) return fail(BSGS_ERR_STATE, "device %d chose another batching", i);
-        free_table(d);
-        // the replica's table state (layout, sizes) is set only after every allocation and copy for this device was queued: a failure
-        // half-way leaves a device WITHOUT a table (bsgs_enqueue then refuses), never one with a layout and null pointers
-        auto replicate = [&]() -> int {
-            HIPCHK(hipMemcpyPeerAsync(d->g2, d->id, s->g2, s->id, s->maxnonce * 64, d->stream));
-            if (s->csr) {
-                const uint64_t bytes = 4 * (s->ht_items + 1) + 4 * s->w;
-                HIPCHK(bsgs_big_malloc(&d->csr, bytes));
-                d->csr_owned = true;
-                HIPCHK(hipMemcpyPeerAsync(d->csr, d->id, s->csr, s->id, bytes, d->stream));
-            }
-            if (s->lines) {
-                HIPCHK(bsgs_lines_malloc(d, (void **)&d->lines, s->lines_bytes));
-                d->lines_owned = true;
-                HIPCHK(hipMemcpyPeerAsync(d->lines, d->id, s->lines, s->id, s->lines_bytes, d->stream));
-            }
-            if (s->ovf) {
-                HIPCHK(bsgs_big_malloc((void **)&d->ovf, s->ovf_n * 8));
-                d->ovf_n = s->ovf_n;
-                HIPCHK(hipMemcpyPeerAsync(d->ovf, d->id, s->ovf, s->id, s->ovf_n * 8, d->stream));
+            if (what & 2u) {
+                free_table(d);
+                if (s->csr) { HIPCHK(bsgs_big_malloc(&d->csr, 4 * (s->ht_items + 1) + 4 * s->w)); d->csr_owned = true; csr[i] = d->csr; }
+                if (s->lines) { HIPCHK(bsgs_lines_malloc(d, (void **)&d->lines, s->lines_bytes)); d->lines_owned = true; lines[i] = d->lines; }
+                if (s->ovf) { HIPCHK(bsgs_big_malloc((void **)&d->ovf, s->ovf_n * 8)); d->ovf_n = s->ovf_n; ovf[i] = d->ovf; }
             }
             return BSGS_OK;
         };
-        rc = replicate();
-        if (rc) {
-            // drain what was queued (this device and the ones before it), drop the partial replica, report the first error
-            const std::string why = bsgs_last_error();
-            for (int k = 1; k <= i; k++) if (devs[k] && devs[k] != s) { (void)hipSetDevice(devs[k]->id); (void)hipStreamSynchronize(devs[k]->stream); }
-            (void)hipSetDevice(d->id);
-            d->lines_owned = true; d->csr_owned = true;
-            free_table(d);
-            return fail(rc, "%s", why.c_str());
+        rc = prepare();
+        if (rc) return fail_all(rc);
+    }
+    if (what & 1u) rc = bsgs_fabric_broadcast(F, g2.data(), s->maxnonce * 64, 0);
+    if (rc == BSGS_OK && (what & 2u) && s->csr) rc = bsgs_fabric_broadcast(F, csr.data(), 4 * (s->ht_items + 1) + 4 * s->w, 0);
+    if (rc == BSGS_OK && (what & 2u) && s->lines) rc = bsgs_fabric_broadcast(F, lines.data(), s->lines_bytes, 0);
+    if (rc == BSGS_OK && (what & 2u) && s->ovf) rc = bsgs_fabric_broadcast(F, ovf.data(), s->ovf_n * 8, 0);
+    if (rc) return fail_all(rc);
+    if (what & 2u)
+        for (int i = 1; i < n; i++) {
+            bsgs_dev *d = devs[i];
+            d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->lines_bytes = s->lines_bytes; d->layout = s->layout; d->bucket_mul = s->bucket_mul;
         }
-        d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->lines_bytes = s->lines_bytes; d->layout = s->layout; d->bucket_mul = s->bucket_mul;
-    }
-    for (int i = 1; i < n; i++) {
-        if (devs[i] == s) continue;
-        HIPCHK(hipSetDevice(devs[i]->id));
-        HIPCHK(hipStreamSynchronize(devs[i]->stream));
-    }
+    bsgs_fabric_close(F);
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return BSGS_OK;
+}
+extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
+{
+    if (n == 1 && devs && devs[0]) return (devs[0]->g2 && devs[0]->layout) ? BSGS_OK : fail(BSGS_ERR_STATE, "devs[0] must hold the giants and the table");
+    return bsgs_broadcast_tables_ex(devs, n, BSGS_TRANSPORT_AUTO, 3u, nullptr, nullptr);
 }
 
 // ---- replica verification -----------------------------------------------------------------------------------------------------

@@ -60,7 +60,7 @@ struct bsgs_dev {
     u64 *ovf = nullptr;         // "lines + overflow list" formats (no CSR on the device): hash set of (bucket << 32 | hash)
     uint64_t ovf_n = 0;         // slots (power of two)
     uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
-    uint32_t bucket_mul = 0;    // 0: ht_items is a power of two, bucket = x & (ht_items - 1); else = ht_items: bucket = floor(xlo * ht_items / 2^32) (extended tables, 128-byte lines)
+    uint32_t bucket_mul = 0;    // 0: ht_items is a power of two, bucket = x & (ht_items - 1); else = ht_items: any number of buckets, bucket from 48 bits of the key (giant_kernel.hip.h bucket_mul48; extended tables, 128-byte lines)
     uint32_t layout = 0;        // probe layout: 1 csr, 2 lines64, 3 lines128 (ovf != NULL: reported as 4 / 5)
     u32 *hitbuf = nullptr;      // device
     u32 *hit_host = nullptr;    // pinned mirror
@@ -121,3 +121,12 @@ int bsgs_ovf_fill(bsgs_dev *d, const u64 *list, uint64_t n, u64 *table, uint64_t
 int bsgs_install_lines(bsgs_dev *d, u32x4 *lines, int lplog, u64 *ovf, uint64_t ovf_n, uint64_t ht_items, uint64_t w,
                        uint64_t overflow_buckets);
 
+
+// startup.hip: the fabric between the engines of one process -- RCCL over xGMI (dlopen'ed on first use) or direct peer copies
+struct bsgs_fabric;
+int bsgs_fabric_open(bsgs_fabric **f, bsgs_dev *const *devs, int n, uint32_t transport);      // transport: BSGS_TRANSPORT_*
+void bsgs_fabric_close(bsgs_fabric *f);
+const char *bsgs_fabric_name(const bsgs_fabric *f);
+int bsgs_fabric_is_rccl(const bsgs_fabric *f);
+int bsgs_fabric_broadcast(bsgs_fabric *f, void *const *bufs, size_t bytes, int root);          // bufs[i] on engine i; every engine's stream drained on return
+int bsgs_fabric_allgather(bsgs_fabric *f, void *const *bufs, size_t slice_bytes);              // in place: engine i's slice number i is there already

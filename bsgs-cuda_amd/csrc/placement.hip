@@ -382,9 +382,31 @@ static hipError_t lines_malloc_chunks(bsgs_dev *d, PieceGrader &G, void **out, s
     prop.location.id = d->id;
     size_t gran = 0;
     if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran || chunk % gran) return hipErrorNotSupported;
-    hipMemAccessDesc acc = {};
-    acc.location = prop.location;
-    acc.flags = hipMemAccessFlagsProtReadWrite;
+    // Access: the owning GPU -- and every GPU that can reach it over xGMI.  A mapping made with the virtual-memory API does NOT inherit hipDeviceEnablePeerAccess:
+    // without the peers here, the replicas of a -w 34 table (bsgs_broadcast_tables, RCCL inside one process, the receive buffers of bsgs_alloc_table_ext_recv)
+    // would fault on the first cross-device copy into or out of these lines.  If the driver refuses the peers the owner alone is granted and the
+    // table stays usable on its own GPU (BSGS_CHUNK_PEER_ACCESS=0 does the same on purpose).
+    std::vector<hipMemAccessDesc> accs(1);
+    accs[0].location = prop.location;
+    accs[0].flags = hipMemAccessFlagsProtReadWrite;
+    {
+        static const bool peers_on = !(getenv("BSGS_CHUNK_PEER_ACCESS") && atoi(getenv("BSGS_CHUNK_PEER_ACCESS")) == 0);
+        int ndev = 0;
+        if (peers_on && hipGetDeviceCount(&ndev) == hipSuccess)
+            for (int p = 0; p < ndev; p++) {
+                int can = 0;
+                if (p == d->id || hipDeviceCanAccessPeer(&can, p, d->id) != hipSuccess || !can) continue;
+                hipMemAccessDesc a = {};
+                a.location.type = hipMemLocationTypeDevice; a.location.id = p; a.flags = hipMemAccessFlagsProtReadWrite;
+                accs.push_back(a);
+            }
+        (void)hipGetLastError();
+    }
+    auto set_access = [&](void *va, size_t bytes) {
+        if (accs.size() > 1 && hipMemSetAccess(va, bytes, accs.data(), accs.size()) == hipSuccess) return hipSuccess;
+        if (accs.size() > 1) { (void)hipGetLastError(); fprintf(stderr, "bsgs: peer access to mapped bucket lines refused by the driver: this table cannot be replicated device-to-device\n"); accs.resize(1); }
+        return hipMemSetAccess(va, bytes, accs.data(), 1);
+    };
     struct C { hipMemGenericAllocationHandle_t h; void *va; float g; };
     std::vector<C> all;
     const size_t need = (bytes + chunk - 1) / chunk;
@@ -434,7 +456,7 @@ static hipError_t lines_malloc_chunks(bsgs_dev *d, PieceGrader &G, void **out, s
         if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < chunk + (2ull << 30)) break;
         if (hipMemCreate(&c.h, chunk, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
         if (!(c.va = vm_fresh_reserve(chunk))) { (void)hipMemRelease(c.h); break; }
-        if (hipMemMap(c.va, chunk, 0, c.h, 0) != hipSuccess || hipMemSetAccess(c.va, chunk, &acc, 1) != hipSuccess) {
+        if (hipMemMap(c.va, chunk, 0, c.h, 0) != hipSuccess || hipMemSetAccess(c.va, chunk, accs.data(), 1) != hipSuccess) {      // a temporary mapping, for grading: the owner only
             (void)hipGetLastError();
             (void)hipMemAddressFree(c.va, chunk); (void)hipMemRelease(c.h);
             break;
@@ -472,7 +494,7 @@ static hipError_t lines_malloc_chunks(bsgs_dev *d, PieceGrader &G, void **out, s
         ok = ok && hipMemMap((char *)big + k * chunk, chunk, 0, c.h, 0) == hipSuccess;
         if (ok) handles.push_back(c.h);
     }
-    ok = ok && hipMemSetAccess(big, need * chunk, &acc, 1) == hipSuccess;
+    ok = ok && set_access(big, need * chunk) == hipSuccess;
     if (!ok) {
         (void)hipGetLastError();
         for (size_t k = 0; k < handles.size(); k++) (void)hipMemUnmap((char *)big + k * chunk, chunk);

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <fstream>
 #include <mutex>
 #include <sstream>
@@ -85,6 +86,10 @@ struct Config {
     bool host_centres = false;                     // -hostcentres: tile centres added on the host and uploaded (the reference's way) instead of the device walk
     bool tune = false;                             // -tune: also choose the bucket-line placement by measurement at start-up (bsgs_tune_placement)
     std::string joblog;                            // test hook: log every dispenser / checkpoint event to this file
+    uint32_t htsz_arg = 25;                        // what the extended-table entry points take as `htsz`: the exponent, or -- `-htsz` with a fraction, `-buckets` -- the bucket COUNT
+    std::string startup = "auto";                  // -startup: how N engines get their replicas -- broadcast | local | allgather | auto (include/bsgs_hip.h BSGS_STARTUP_*)
+    std::string transport = "auto";                // -transport: rccl | peer | auto
+    bool file_search = false;                      // -sf (hidden in the reference too, 1_9_7File.pb:907-918): htCPU looked up in the file instead of RAM; accepted, the resolver keeps it in RAM
 };
 
 static void die(const std::string &msg)
@@ -111,7 +116,11 @@ static void usage(const Config &c)
            "-noverify    Several GPUs: skip the comparison of the replicas (table checksums, one probe tile) after they were made\n"
            "-refquirks   Reproduce the reference kernel's -Gy borrow bug bit for bit (default: correct arithmetic, finds a superset)\n"
            "-hostcentres Add the tile centres on the host and upload them (default: derived on the GPU from the tile counter)\n"
-           "-tune        Time a few placements of the GPU buffers at start-up and keep the fastest (the engine already places them by grade)\n",
+           "-tune        Time a few placements of the GPU buffers at start-up and keep the fastest (the engine already places them by grade)\n"
+           "-startup     Several GPUs: broadcast (GPU 0 holds the table, the others receive it over xGMI), local (every GPU builds / uploads its own),\n"
+           "             allgather (extended tables: every GPU builds 1/N of the bucket lines, then all-gather); default: local for extended tables, else broadcast\n"
+           "-transport   Several GPUs: rccl | peer (direct peer copies) | auto (RCCL when the GPUs are distinct and librccl loads)\n"
+           "-buckets     Extended table: the number of buckets itself (any number below 2^32, 128-byte lines), e.g. -w 35 -buckets 1610612736; -htsz 30.585 says the same\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
 }
 
@@ -137,7 +146,19 @@ static Config parse_args(int argc, char **argv)
             if (d <= 36.0) { c.w = (uint64_t)std::pow(2.0, d); printf("Items number set to 2^%s=%llu\n", v.c_str(), (unsigned long long)c.w); }
             else { c.w = strtoull(v.c_str(), nullptr, 10); printf("Items number set to %llu = 2^%f\n", (unsigned long long)c.w, std::log2((double)c.w)); }
         }
-        else if (a == "-htsz") { c.htsz = (uint32_t)atoi(next().c_str()); printf("HT size set to 2^%u\n", c.htsz); }
+        else if (a == "-htsz") {
+            const std::string v = next();
+            const double d = atof(v.c_str());
+            c.htsz = (uint32_t)d; c.htsz_arg = c.htsz;
+            if (d != std::floor(d)) {               // a fraction (as -w takes one, 1_9_7File.pb:1009-1022): extended tables may have any number of buckets
+                c.htsz_arg = (uint32_t)std::llround(std::pow(2.0, d));
+                printf("HT size set to 2^%s=%u buckets (extended table)\n", v.c_str(), c.htsz_arg);
+            } else printf("HT size set to 2^%u\n", c.htsz);
+        }
+        else if (a == "-buckets") { c.htsz_arg = (uint32_t)strtoull(next().c_str(), nullptr, 10); c.htsz = 0; while ((2ull << c.htsz) <= c.htsz_arg) c.htsz++; printf("HT size set to %u buckets (extended table)\n", c.htsz_arg); }
+        else if (a == "-sf") { c.file_search = atoi(next().c_str()) != 0; printf(c.file_search ? "Search in file\n" : "Search in RAM\n"); }
+        else if (a == "-startup") { c.startup = next(); for (auto &ch : c.startup) ch = (char)tolower(ch); }
+        else if (a == "-transport") { c.transport = next(); for (auto &ch : c.transport) ch = (char)tolower(ch); }
         else if (a == "-infile") { c.infile = next(); printf("Will be used file: %s\n", c.infile.c_str()); }
         else if (a == "-wl") { c.recovery_file = next(); printf("Recovery work file: %s\n", c.recovery_file.c_str()); }
         else if (a == "-wt") { c.wt = std::max(30, atoi(next().c_str())); printf("Saving timer every %d seconds\n", c.wt); }
@@ -160,6 +181,12 @@ static Config parse_args(int argc, char **argv)
         printf("-w above the reference limit 3069485951: extended table in GPU memory, no HT files\n");
     }
     if (c.htsz > 31 || c.htsz < 1) die("-htsz must be 1..31");
+    if (c.htsz_arg > 31) {
+        if (!(c.htsz_arg & (c.htsz_arg - 1))) { c.htsz = 0; while ((1u << c.htsz) < c.htsz_arg) c.htsz++; c.htsz_arg = c.htsz; }      // a power of two after all
+        else { c.ext = true; printf("%u buckets (not a power of two): extended table in GPU memory, no HT files\n", c.htsz_arg); }
+    }
+    if (c.startup != "auto" && c.startup != "broadcast" && c.startup != "local" && c.startup != "allgather") die("-startup: broadcast | local | allgather | auto");
+    if (c.transport != "auto" && c.transport != "rccl" && c.transport != "peer") die("-transport: rccl | peer | auto");
     if (c.p & 1) die("-p must be even");
     if (!c.t || !c.b || !c.p) die("-t -b -p must be non-zero");
     return c;
@@ -177,11 +204,19 @@ static bool read_file(const std::string &path, std::vector<uint8_t> &out, uint64
     f.read((char *)out.data(), (std::streamsize)n);
     return (bool)f;
 }
+// written under a temporary name and renamed after a checked flush: a run that ends while the file is being written (a later start-up error, a full disk)
+// leaves a `.part` file behind, never a short table under the reference's name
 static void write_file(const std::string &path, const void *p, uint64_t n)
 {
-    std::ofstream f(path, std::ios::binary);
-    if (!f) die("Can`t create " + path);
-    f.write((const char *)p, (std::streamsize)n);
+    const std::string tmp = path + ".part";
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) die("Can`t create " + tmp);
+        f.write((const char *)p, (std::streamsize)n);
+        f.flush();
+        if (!f) { remove(tmp.c_str()); die("Can`t write " + path + " (" + std::to_string(n) + " bytes): disk full?"); }
+    }
+    if (rename(tmp.c_str(), path.c_str()) != 0) die("Can`t rename " + tmp);
 }
 
 #define CK(call) do { int rc_ = (call); if (rc_ != BSGS_OK) die(std::string("error " #call "-") + std::to_string(rc_) + ": " + bsgs_last_error()); } while (0)
@@ -444,23 +479,105 @@ static bsgs_dev *open_dev(int gpu)
     printf("GPU #%d %s memory %.0f/%.0f MB\n", gpu, name, fr / 1048576.0, tot / 1048576.0);
     return dev;
 }
-static void load_first(const Shared &S, int gpu, bsgs_dev *dev, const std::vector<uint8_t> &htgpu, const std::vector<uint8_t> &g2)
+// the extended table's line size: 64-byte lines up to ~9 entries per bucket (the over-full 1 % go through the overflow set: measured faster AND half the memory of
+// 128-byte lines at -w 34 -htsz 31); beyond that, and for a bucket count that is not a power of two, 128-byte lines
+static uint32_t ext_layout(const Config &c, uint64_t free_bytes)
 {
-    uint64_t fr = 0, tot = 0;
-    CK(bsgs_dev_meminfo(dev, &fr, &tot));
-    CK(bsgs_upload_g2(dev, g2.data(), S.cfg.t, S.cfg.b, S.cfg.p));
-    if (S.cfg.ext) {
-        const auto t0 = std::chrono::steady_clock::now();
-        const double load = (double)S.cfg.w / (double)(1ull << S.cfg.htsz);
-        // 64-byte lines up to ~9 entries per bucket (the over-full 1 % go through the overflow set: measured faster AND half
-        // the memory of 128-byte lines at -w 34 -htsz 31); beyond that 128-byte lines if they fit
-        const bool fits128 = (128ull << S.cfg.htsz) + (24ull << 30) < fr;
-        CK(bsgs_build_baby_table_ext(dev, S.cfg.w, S.cfg.htsz, load > 9.0 && fits128 ? BSGS_TABLE_LINES128_LIST : BSGS_TABLE_LINES64_LIST));
+    const uint64_t buckets = c.htsz_arg > 31 ? c.htsz_arg : 1ull << c.htsz_arg;
+    if (c.htsz_arg > 31) return BSGS_TABLE_LINES128_LIST;
+    const double load = (double)c.w / (double)buckets;
+    const bool fits128 = 128ull * buckets + (24ull << 30) < free_bytes;
+    return load > 9.0 && fits128 ? BSGS_TABLE_LINES128_LIST : BSGS_TABLE_LINES64_LIST;
+}
+static uint32_t transport_code(const Config &c) { return c.transport == "rccl" ? BSGS_TRANSPORT_RCCL : c.transport == "peer" ? BSGS_TRANSPORT_PEER : BSGS_TRANSPORT_AUTO; }
+static const char *transport_name(uint32_t t) { return t == BSGS_TRANSPORT_RCCL ? "RCCL over xGMI" : t == BSGS_TRANSPORT_PEER ? "peer copies" : "none"; }
+static void print_placement(int gpu, size_t gi, bsgs_dev *dev)
+{
+    uint32_t info[5] = {0, 0, 0, 0, 0}; float grade[2] = {0.f, 0.f};
+    CK(bsgs_chain_placement(dev, info, grade));
+    printf("GPU #%d engine %zu: chain scratch in %u piece(s) of %u tiles, %u graded, reserved group: %s\n", gpu, gi, info[0], info[1], info[2], info[4] ? "yes" : "no");
+}
+// fn(gi) for every engine, one host thread per GPU: engines on distinct GPUs run concurrently, engines that share a GPU (-d 0,0) one after the other
+static void per_gpu(const std::vector<int> &gpus, const std::function<void(size_t)> &fn)
+{
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < gpus.size(); i++) {
+        bool first = true;
+        for (size_t j = 0; j < i; j++) first &= gpus[j] != gpus[i];
+        if (!first) continue;
+        th.emplace_back([&, i] { for (size_t k = i; k < gpus.size(); k++) if (gpus[k] == gpus[i]) fn(k); });
+    }
+    for (auto &t : th) t.join();
+}
+
+// Devices are loaded once (1_9_7File.pb:2181-2357) and serve every public key of the run.  The reference gives every GPU its own upload of the two host buffers over
+// PCIe (1_9_7File.pb:2337, 2350, 4769-4843).  Here, with several engines (-startup):
+//   broadcast  engine 0 takes the giants and the table from the host (or builds the extended table), the others receive replicas over xGMI (RCCL, or peer copies);
+//   local      every engine takes / builds its own, concurrently: the reference's shape for file tables, and NO link traffic at all for extended tables (default there);
+//   allgather  extended tables: every engine builds the lines of 1/N of the buckets, then all-gather.
+// Every engine allocates its chain scratch (placed by grade: the reference's cuMemAlloc_v2 before its loop, 1_9_7File.pb:2251) right after its table.
+static void load_engines(const Shared &S, const std::vector<int> &gpus, const std::vector<bsgs_dev *> &devs, const std::vector<uint8_t> &htgpu, const std::vector<uint8_t> &g2)
+{
+    const Config &c = S.cfg;
+    const size_t n = devs.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    std::string strategy = c.startup;
+    if (strategy == "auto") strategy = c.ext ? "local" : "broadcast";
+    if (!c.ext && strategy == "allgather") { printf("-startup allgather applies to extended tables: file tables are broadcast\n"); strategy = "broadcast"; }
+    if (n == 1) strategy = "local";
+    const bool local = strategy == "local";
+    // ---- giants
+    if (local) per_gpu(gpus, [&](size_t gi) { CK(bsgs_upload_g2(devs[gi], g2.data(), c.t, c.b, c.p)); });
+    else {
+        CK(bsgs_upload_g2(devs[0], g2.data(), c.t, c.b, c.p));
+        uint32_t used = 0; double s = 0.0;
+        CK(bsgs_broadcast_tables_ex(devs.data(), (int)n, transport_code(c), 1u, &used, &s));
+        printf("Giants replicated to %zu more GPU engine(s) by %s in %.2fs\n", n - 1, transport_name(used), s);
+    }
+    printf("[startup] %-44s %.3fs\n", "giants on every engine", secs());
+    // ---- table
+    if (c.ext) {
+        uint64_t fr = 0, tot = 0;
+        CK(bsgs_dev_meminfo(devs[0], &fr, &tot));
+        const uint32_t layout = ext_layout(c, fr);
+        const uint32_t strat = strategy == "broadcast" ? BSGS_STARTUP_BROADCAST : strategy == "allgather" ? BSGS_STARTUP_ALLGATHER : BSGS_STARTUP_LOCAL;
+        std::vector<bsgs_startup_report> rep(n);
+        CK(bsgs_startup_ext_tables(devs.data(), (int)n, c.w, c.htsz_arg, layout, strat, transport_code(c), rep.data()));
+        static const char *names[3] = {"broadcast", "local", "allgather"};
+        for (size_t gi = 0; gi < n; gi++) {
+            const bsgs_startup_report &r = rep[gi];
+            printf("[startup] engine %zu (GPU #%d) extended table, strategy %s%s: buffers %.2fs, build %.2fs, transfer %.2fs (%.1f GiB received, %s), overflow set %.2fs, install %.2fs, "
+                   "chain scratch %.2fs; done at %.2fs\n", gi, gpus[gi], names[r.strategy], r.strategy != strat ? " (fallback)" : "", r.alloc_s, r.build_s, r.transfer_s,
+                   r.bytes_received / 1073741824.0, transport_name(r.transport), r.set_s, r.install_s, r.prepare_s, r.total_s);
+        }
         uint32_t lay = 0; uint64_t bytes = 0, ovf = 0;
-        CK(bsgs_table_info(dev, &lay, &bytes, &ovf));
-        printf("GPU #%d extended table: %llu items, %.1f GiB in memory, %llu over-full buckets, built in %.1fs\n", gpu, (unsigned long long)S.cfg.w,
-               bytes / 1073741824.0, (unsigned long long)ovf, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    } else CK(bsgs_upload_htgpu(dev, htgpu.data(), 1ull << S.cfg.htsz, S.cfg.w, BSGS_TABLE_AUTO));
+        CK(bsgs_table_info(devs[0], &lay, &bytes, &ovf));
+        printf("Extended table: %llu items, %.1f GiB in memory per GPU, %llu over-full buckets, %zu engine(s) ready in %.1fs\n", (unsigned long long)c.w, bytes / 1073741824.0,
+               (unsigned long long)ovf, n, secs());
+        for (size_t gi = 0; gi < n; gi++) print_placement(gpus[gi], gi, devs[gi]);
+    } else if (local) {
+        per_gpu(gpus, [&](size_t gi) {
+            CK(bsgs_upload_htgpu(devs[gi], htgpu.data(), 1ull << c.htsz, c.w, BSGS_TABLE_AUTO));
+            CK(bsgs_prepare(devs[gi]));
+        });
+        if (n > 1) printf("Tables uploaded to every GPU engine from the host (the reference's way, 1_9_7File.pb:2337, 2350) in %.2fs\n", secs());
+        for (size_t gi = 0; gi < n; gi++) print_placement(gpus[gi], gi, devs[gi]);
+    } else {
+        CK(bsgs_upload_htgpu(devs[0], htgpu.data(), 1ull << c.htsz, c.w, BSGS_TABLE_AUTO));
+        // the first engine's chain scratch BEFORE the replicas: an engine that reserved a memory group for it (tables above 40 GiB) hands the unused part back
+        // here, which matters when a second engine shares the GPU (-d 0,0)
+        CK(bsgs_prepare(devs[0]));
+        print_placement(gpus[0], 0, devs[0]);
+        uint32_t used = 0; double s = 0.0;
+        CK(bsgs_broadcast_tables_ex(devs.data(), (int)n, transport_code(c), 2u, &used, &s));
+        uint32_t lay = 0; uint64_t bytes = 0, ovf = 0;
+        CK(bsgs_table_info(devs[0], &lay, &bytes, &ovf));
+        printf("Tables replicated to %zu more GPU engine(s) by %s in %.2fs (%.2f GiB each, %.1f GB/s per destination)\n", n - 1, transport_name(used), s, bytes / 1073741824.0,
+               s > 0 ? bytes / 1e9 / s : 0.0);
+        for (size_t gi = 1; gi < n; gi++) { CK(bsgs_prepare(devs[gi])); print_placement(gpus[gi], gi, devs[gi]); }
+    }
+    printf("[startup] %-44s %.3fs\n", (std::string("tables on every engine (") + strategy + ")").c_str(), secs());
 }
 
 // A replica that differs from the first engine's tables in one byte loses keys silently.  The reference uploads every GPU from ONE host buffer
@@ -470,7 +587,10 @@ static void verify_replicas(const std::vector<int> &gpus, const std::vector<bsgs
 {
     if (const char *e = getenv("BSGS_TEST_CORRUPT_ENGINE")) {         // test hook: one flipped bit in one engine's table must stop the run
         const size_t k = (size_t)atoi(e);
-        if (k < devs.size()) CK(bsgs_debug_corrupt_table(devs[k], 4096 + 5, 0x10));
+        if (k < devs.size()) {
+            fprintf(stderr, "BSGS_TEST_CORRUPT_ENGINE=%zu: TEST HOOK -- one bit of engine %zu's table is flipped before the replicas are compared (this run must stop)\n", k, k);
+            CK(bsgs_debug_corrupt_table(devs[k], 4096 + 5, 0x10));
+        }
     }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::array<uint64_t, 4>> sums(devs.size());
@@ -604,7 +724,7 @@ static void tune(int gpu)
 static std::string fingerprint(const Config &c)
 {
     std::ostringstream s;
-    s << c.t << c.b << c.p << c.w << c.pk << c.pke << c.htsz;     // Str(t)+Str(b)+Str(p)+Str(w)+pk+pke+Str(htsz)  (4635-4636)
+    s << c.t << c.b << c.p << c.w << c.pk << c.pke << (c.htsz_arg > 31 ? c.htsz_arg : c.htsz);     // Str(t)+Str(b)+Str(p)+Str(w)+pk+pke+Str(htsz)  (4635-4636); a bucket count stands for htsz
     return sha1_hex(s.str());
 }
 static void save_checkpoint(Shared &S)
@@ -741,7 +861,8 @@ int main(int argc, char **argv)
     // files that were just generated are written by background threads while the start-up goes on (upload, bucket lines, scratch): the buffers they read
     // stay alive until `flush_writers` -- before the staging copies are released, and before any return
     std::vector<std::thread> writers;
-    auto flush_writers = [&]() { for (auto &w : writers) w.join(); writers.clear(); };
+    std::string saved_msg;
+    auto flush_writers = [&]() { for (auto &w : writers) w.join(); writers.clear(); if (!saved_msg.empty()) { fputs(saved_msg.c_str(), stdout); saved_msg.clear(); } };
     const uint64_t gpu_bytes = 4 * (ht_items + 1) + 4 * c.w, cpu_bytes = 4 * (ht_items + 1) + 8 * c.w, g2_bytes = 64 * S.maxnonce;
     bsgs_dev *d0 = nullptr;
     auto dev0 = [&]() { if (!d0) CK(bsgs_dev_open(gpus[0], &d0)); return d0; };
@@ -765,7 +886,7 @@ int main(int argc, char **argv)
         g2.resize(g2_bytes);
         CK(bsgs_download_g2(dev0(), g2.data(), g2_bytes));
         writers.emplace_back([&]() { write_file(f_g2, g2.data(), g2_bytes); });
-        printf("Save BIN file:%s\n", f_g2.c_str());
+        saved_msg = "Save BIN file:" + f_g2 + "\n";                  // printed once the file IS on disk (flush_writers)
     }
     if (d0) { bsgs_dev_close(d0); d0 = nullptr; }
     stage("table + giants files (load, or build + save)");
@@ -815,30 +936,10 @@ int main(int argc, char **argv)
         printf("Resolver table: 2^%u multiples of G in %.1fs\n", S.mini.mb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     std::vector<bsgs_dev *> devs(gpus.size(), nullptr);
-    {   // the first GPU takes the giants and the table from the host (or builds the extended table); every other GPU -- the same id may
-        // be listed twice: two engines, two driver threads on one GPU -- gets its replica device-to-device over xGMI
-        const auto t0 = std::chrono::steady_clock::now();
+    {
         for (size_t gi = 0; gi < gpus.size(); gi++) devs[gi] = open_dev(gpus[gi]);
-        load_first(S, gpus[0], devs[0], htgpu, g2);
-        // the chain scratch, placed by grade, is part of the start-up (the reference's cuMemAlloc_v2 before its loop, 1_9_7File.pb:2251), and
-        // it is allocated BEFORE the replicas: an engine that reserved a memory group for it (tables above 40 GiB) hands the unused part of
-        // the reserve back here, which matters when a second engine shares the GPU (-d 0,0)
-        auto prepare = [&](size_t gi) {
-            CK(bsgs_prepare(devs[gi]));
-            uint32_t info[5] = {0, 0, 0, 0, 0}; float grade[2] = {0.f, 0.f};
-            CK(bsgs_chain_placement(devs[gi], info, grade));
-            printf("GPU #%d engine %zu: chain scratch in %u piece(s) of %u tiles, %u graded, reserved group: %s\n", gpus[gi], gi, info[0], info[1], info[2],
-                   info[4] ? "yes" : "no");
-        };
-        prepare(0);
-        if (devs.size() > 1) {
-            const auto t1 = std::chrono::steady_clock::now();
-            CK(bsgs_broadcast_tables(devs.data(), (int)devs.size()));
-            printf("Tables replicated to %zu more GPU engine(s) device-to-device in %.2fs\n", devs.size() - 1, std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
-            for (size_t gi = 1; gi < devs.size(); gi++) prepare(gi);
-            if (c.verify_replicas) verify_replicas(gpus, devs);
-        }
-        (void)t0;
+        load_engines(S, gpus, devs, htgpu, g2);
+        if (devs.size() > 1 && c.verify_replicas) verify_replicas(gpus, devs);
         if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }
     }
     stage("upload, bucket lines, chain scratch, replicas");

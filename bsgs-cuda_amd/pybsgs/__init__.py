@@ -26,7 +26,7 @@ NATIVE_SYMBOLS = [
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_quirk_count", "bsgs_broadcast_tables",
     "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_chain_grades", "bsgs_debug_grade_rule", "bsgs_debug_xcd_profile",
     "bsgs_table_checksum", "bsgs_debug_corrupt_table", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
-    "bsgs_table_census", "bsgs_table_lookup",
+    "bsgs_table_census", "bsgs_table_lookup", "bsgs_broadcast_tables_ex", "bsgs_startup_ext_tables", "bsgs_build_baby_table_ext_slice", "bsgs_build_overflow_set", "bsgs_debug_fabric_selftest",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -124,6 +124,11 @@ def lib():
             "bsgs_debug_last_kernel": [vp, C.c_char_p, C.c_int],
             "bsgs_table_checksum": [vp, C.POINTER(C.c_uint64)],
             "bsgs_table_census": [vp, C.POINTER(C.c_uint64)],
+            "bsgs_broadcast_tables_ex": [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)],
+            "bsgs_startup_ext_tables": [C.POINTER(vp), C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp],
+            "bsgs_build_baby_table_ext_slice": [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+            "bsgs_build_overflow_set": [vp, vp, C.c_uint64, vp, C.c_uint64],
+            "bsgs_debug_fabric_selftest": [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)],
             "bsgs_table_lookup": [vp, vp, C.c_uint64, vp],
             "bsgs_debug_corrupt_table": [vp, C.c_uint64, C.c_uint32],
             "bsgs_debug_table_owner": [vp, C.POINTER(C.c_int)],
@@ -147,7 +152,9 @@ def lib():
             "bsgs_debug_xcd_profile": [vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_float)],
         }
         for name, args in sig.items():
-            fn = getattr(L, name)
+            fn = getattr(L, name, None)
+            if fn is None:                       # an older build loaded through BSGS_LIB_PATH for an A/B run: the call site raises if it is ever needed
+                continue
             fn.argtypes = args
             fn.restype = C.c_int
         _lib = L
@@ -173,6 +180,39 @@ def broadcast_tables(devices):
     """replicas of devices[0]'s giants and table on the other Device objects (device-to-device copies; the same GPU may appear twice)"""
     arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
     _chk(lib().bsgs_broadcast_tables(arr, len(devices)))
+
+
+TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1, 2
+STARTUP_BROADCAST, STARTUP_LOCAL, STARTUP_ALLGATHER = 0, 1, 2
+
+
+class StartupReport(C.Structure):
+    _fields_ = [("alloc_s", C.c_double), ("build_s", C.c_double), ("transfer_s", C.c_double), ("set_s", C.c_double), ("install_s", C.c_double),
+                ("prepare_s", C.c_double), ("total_s", C.c_double), ("bytes_received", C.c_uint64), ("strategy", C.c_uint32), ("transport", C.c_uint32)]
+
+
+def startup_ext_tables(devices, w, htsz, layout, strategy, transport=TRANSPORT_AUTO):
+    """extended table on every Device of one process by one of the three start-up strategies (include/bsgs_hip.h BSGS_STARTUP_*); returns one dict per engine"""
+    arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    rep = (StartupReport * len(devices))()
+    _chk(lib().bsgs_startup_ext_tables(arr, len(devices), w, htsz, layout, strategy, transport, C.cast(rep, C.c_void_p)))
+    return [{k: getattr(r, k) for k, _ in StartupReport._fields_} for r in rep]
+
+
+def broadcast_tables_ex(devices, transport=TRANSPORT_AUTO, what=3):
+    """replicas of devices[0]'s giants (what & 1) and table (what & 2) on the other Devices; returns (transport used, seconds)"""
+    arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    used, secs = C.c_uint32(), C.c_double()
+    _chk(lib().bsgs_broadcast_tables_ex(arr, len(devices), transport, what, C.byref(used), C.byref(secs)))
+    return used.value, secs.value
+
+
+def fabric_selftest(devices, transport, nbytes):
+    """(mismatching words after the broadcast, after the all-gather, transport used) of the transport test (bsgs_debug_fabric_selftest)"""
+    arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
+    bad, used = (C.c_uint64 * 2)(), C.c_uint32()
+    _chk(lib().bsgs_debug_fabric_selftest(arr, len(devices), transport, nbytes, bad, C.byref(used)))
+    return int(bad[0]), int(bad[1]), used.value
 
 
 def alloc_stats():
@@ -266,6 +306,15 @@ class Device:
         n, ob = C.c_uint64(0), C.c_uint64(0)
         _chk(self.L.bsgs_build_baby_table_ext_device(self.h, w, htsz, layout, C.c_void_p(lines_dptr), C.c_void_p(ovf_dptr), ovf_cap, C.byref(n), C.byref(ob)))
         return n.value, ob.value
+
+    def build_baby_table_ext_slice(self, w, htsz, layout, lines_dptr, part, nparts, list_dptr, list_cap):
+        """the lines of 1/nparts of the buckets, in place inside the full line buffer; returns (entries in the slice's overflow list, over-full lines of the slice)"""
+        n, ob = C.c_uint64(0), C.c_uint64(0)
+        _chk(self.L.bsgs_build_baby_table_ext_slice(self.h, w, htsz, layout, C.c_void_p(lines_dptr), part, nparts, C.c_void_p(list_dptr), list_cap, C.byref(n), C.byref(ob)))
+        return n.value, ob.value
+
+    def build_overflow_set(self, list_dptr, n, set_dptr, slots):
+        _chk(self.L.bsgs_build_overflow_set(self.h, C.c_void_p(list_dptr), n, C.c_void_p(set_dptr), slots))
 
     def install_table_ext_device(self, lines_dptr, ovf_dptr, ovf_n, overflow_buckets, w, htsz, layout):
         _chk(self.L.bsgs_install_table_ext_device(self.h, C.c_void_p(lines_dptr), C.c_void_p(ovf_dptr), ovf_n, overflow_buckets, w, htsz, layout))

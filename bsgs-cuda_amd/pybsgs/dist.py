@@ -70,6 +70,29 @@ def broadcast_table(img, src=0):
     return time.time() - t0
 
 
+def allgather_slices(full, slice_bytes):
+    """in-place all-gather of a uint8 tensor made of world equal slices (this rank's slice, number rank, already there): the line slices of the "1/N each +
+    all-gather" start-up.  RCCL: one ncclAllGather (viewed as int64: the element count of a 16 GiB slice stays below 2^31); gloo (CPU tests, --same-device):
+    one staged broadcast per slice.  Returns seconds spent."""
+    import time
+    if _alone():
+        return 0.0
+    world, rank = td.get_world_size(), td.get_rank()
+    assert full.numel() == world * slice_bytes and slice_bytes % 8 == 0
+    if full.is_cuda and td.get_backend() != "gloo":
+        torch.cuda.synchronize()
+        t0 = time.time()
+        wide = full.view(torch.int64)
+        n = slice_bytes // 8
+        td.all_gather_into_tensor(wide, wide[rank * n:(rank + 1) * n])
+        torch.cuda.synchronize()
+        return time.time() - t0
+    t = 0.0
+    for r in range(world):
+        t += broadcast_table(full[r * slice_bytes:(r + 1) * slice_bytes], src=r)
+    return t
+
+
 class DeviceMemory:
     """a raw device allocation of the engine (pointer, bytes) as something torch can wrap without copying
     (torch.as_tensor(DeviceMemory(...), device=...) -> uint8 tensor over the same memory): the receive buffers of a broadcast table"""

@@ -40,6 +40,12 @@ import hashlib
 same, sums = D.all_equal([hashlib.sha256(table).hexdigest(), len(g2)])
 bad, _ = D.all_equal([hashlib.sha256(table).hexdigest(), len(g2) + (1 if rank == 1 else 0)])
 assert same and not bad and len(sums) == world and D.XGMI_LINK_GBPS > 100
+# the "1/N each + all-gather" start-up (bench.py --startup-strategy allgather): every rank holds its own slice of one buffer, in place; afterwards all hold all
+full = torch.zeros(world * 4096, dtype=torch.uint8)
+full[rank * 4096:(rank + 1) * 4096] = torch.arange(4096, dtype=torch.int32).add(rank * 7).remainder(251).to(torch.uint8)
+D.allgather_slices(full, 4096)
+for r in range(world):
+    assert torch.equal(full[r * 4096:(r + 1) * 4096], torch.arange(4096, dtype=torch.int32).add(r * 7).remainder(251).to(torch.uint8)), r
 steps = D.reduce_sum_int(len(mine) * 2 * fx["t"] * fx["b"] * fx["p"])
 tmax = D.reduce_max([0.5 + rank])[0]
 json.dump({"rank": rank, "world": world, "gathered": recs, "hits": hits, "tiles": [k for k, _ in mine], "steps": steps, "tmax": tmax},

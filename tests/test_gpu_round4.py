@@ -76,7 +76,7 @@ def test_bench_turns_red_when_rank_1_holds_a_corrupted_replica(table):
     """`bench.py --gpus 2 --same-device` with BENCH_CORRUPT_RANK=1: rank 1 flips one bit of the table it received; the run must end with a
     non-zero exit code, no rate, and say which rank differs"""
     common = ["--w", "26", "--htsz", "25", "--tiles-per-launch", "48", "--steps", "2", "--warmup", "1", "--warmup-s", "0", "--sustain-s", "0",
-              "--no-cpu-baseline", "--no-solve", "--no-pmc", "--gpus", "2", "--same-device"] + (["--force-ext"] if table == "extended" else [])
+              "--no-cpu-baseline", "--no-solve", "--no-pmc", "--gpus", "2", "--same-device"] + (["--force-ext", "--startup-strategy", "broadcast"] if table == "extended" else [])
     bad = _bench(common, env_extra={"BENCH_CORRUPT_RANK": "1"}, expect_rc="nonzero")
     assert bad["value"] is None and bad["error"] == "replica verification FAILED" and bad["ranks_differing_from_rank0"] == [1]
     assert bad["verification"]["table_checksum_equal"] is False
