@@ -86,6 +86,7 @@ extern "C" const char *bsgs_build_info(void)
         SW(FE_SQR_VIA_MUL);
 #endif
         if (BSGS_PAIR2_WAVES != 4) add("BSGS_PAIR2_WAVES=" BSGS_STR(BSGS_PAIR2_WAVES));
+        if (BSGS_PAIR2_WAVES128 != 3) add("BSGS_PAIR2_WAVES128=" BSGS_STR(BSGS_PAIR2_WAVES128));
         if (BSGS_TILE_CHUNK != 64u) add("BSGS_TILE_CHUNK=" BSGS_STR(BSGS_TILE_CHUNK));
         if (BSGS_NT_CHAIN != 1) add("BSGS_NT_CHAIN=" BSGS_STR(BSGS_NT_CHAIN));
         if (BSGS_NT_LINES != 0) add("BSGS_NT_LINES=" BSGS_STR(BSGS_NT_LINES));
@@ -300,6 +301,13 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
 }
 
 static bool lines_layout(const bsgs_dev *d) { return d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128; }
+// threads per workgroup of the tile kernel: four waves with 64-byte lines (10 KiB of LDS per wave: four blocks fill a CU), two with 128-byte lines (14 KiB per wave: five
+// blocks = ten waves per CU; four-wave blocks would stop at eight).  BSGS_LINES128_BLOCK=256 is the A-B switch.
+static unsigned tile_block(const bsgs_dev *d)
+{
+    static const unsigned b128 = getenv("BSGS_LINES128_BLOCK") ? (unsigned)atoi(getenv("BSGS_LINES128_BLOCK")) : 128u;
+    return d->layout == BSGS_TABLE_LINES128 && (b128 == 128u || b128 == 256u) ? b128 : d->block_size;
+}
 // giants per stored running product of the tile kernel a launch with batch length `pi` takes: 4 / 2 = the chained kernel (giant_pair2_kernel,
 // QUAD or not), 1 = the per-giant kernel (CSR layout, odd batch lengths, BSGS_KERNEL_VARIANT=0)
 static uint32_t chain_group(const bsgs_dev *d, uint32_t pi)
@@ -319,7 +327,7 @@ static int ensure_chain(bsgs_dev *d, uint64_t tiles, bool full = false)
     static const uint64_t pad_env = getenv("BSGS_CHAIN_PAD") ? strtoull(getenv("BSGS_CHAIN_PAD"), nullptr, 10) : 0;
     d->chain_pad = chained ? (uint32_t)(pad_env / 16) : 0;
     // the chained kernel's scratch is [tile][block][group][2][block size]: whole blocks (the tail block is padded)
-    const uint64_t threads_padded = ((uint64_t)d->Ti + d->block_size - 1) / d->block_size * d->block_size;
+    const uint64_t threads_padded = ((uint64_t)d->Ti + tile_block(d) - 1) / tile_block(d) * tile_block(d);
     const uint64_t per_tile = (chained ? threads_padded * d->pi * (32 / group) : d->maxnonce * 32) + (uint64_t)d->chain_pad * 16;
     const uint64_t bytes = per_tile * tiles;
     static const bool pieces_on = !(getenv("BSGS_CHAIN_PIECES") && atoi(getenv("BSGS_CHAIN_PIECES")) == 0);
@@ -692,7 +700,7 @@ static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles)
     if (d->narrow_off || d->narrow_env_off || d->digest || d->debug_flags || d->phase_probe) return nullptr;
     if (chain_group(d, d->pi) != 4) return nullptr;
     if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) return nullptr;        // the quirk list is indexed by the default batching
-    const uint32_t pi = narrow_pi(d->maxnonce, d->pi, ntiles, (uint32_t)d->prop.multiProcessorCount, d->block_size);
+    const uint32_t pi = narrow_pi(d->maxnonce, d->pi, ntiles, (uint32_t)d->prop.multiProcessorCount, d->block_size);      // (the rule is stated for 256-thread blocks; a two-wave block divides whatever it allows)
     if (pi == d->pi) return nullptr;
     for (const auto &b : d->narrow) if (b.pi == pi) return &b;
     // build it: 64 bytes per giant once more.  Not at the expense of anything else: only while twice that much (and 2 GiB) is free
@@ -735,7 +743,7 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
         A.chain = nullptr; A.chain_mode = d->chain_piece_log + 1;
         for (size_t k = 0; k < d->chain_pieces.size(); k++) A.chain_piece[k] = d->chain_pieces[k];
     }
-    const unsigned bs = d->block_size;
+    const unsigned bs = tile_block(d);
     if ((d->flags & BSGS_FLAG_REFERENCE_QUIRKS) && !d->quirk_host.empty()) {
         // the reference's own P - G arithmetic for the listed giants; bsgs_collect drops the hot loop's records for them
         const uint32_t nfix = (uint32_t)d->quirk_host.size() * ntiles;
@@ -747,7 +755,8 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     const uint32_t group = chain_group(d, pi);
     // chained kernel, per wave: two probe slots (QUAD: one probe slot + the two 2 KiB temporaries) + the 2 KiB S stash: 4 blocks fill the 160 KiB of a CU exactly
     const bool l128 = d->layout == BSGS_TABLE_LINES128;
-    const size_t lds = group > 1 ? (size_t)(bs / 64) * (2 * (l128 ? 8192 : 4096) + 2048) : 0;
+    const size_t slot = l128 ? 8192 : 4096;
+    const size_t lds = group > 1 ? (size_t)(bs / 64) * ((group == 4 ? slot + 4096 : 2 * slot) + 2048) : 0;
     const bool dbg = d->debug_flags != 0 || d->phase_probe;
     if (d->layout == BSGS_TABLE_LINES64) HIPCHK(bsgs_launch_tile_lines64(A, grid, block, lds, st, group, dbg, &d->last_kernel));
     else if (l128)                       HIPCHK(bsgs_launch_tile_lines128(A, grid, block, lds, st, group, dbg, &d->last_kernel));

@@ -317,6 +317,96 @@ __device__ __forceinline__ void dpf_mul512(double (&V)[12], const fd6 &a, const 
     V[11] = carry;
 }
 
+// ---------------------------------------------------------------- unsaturated limbs: N limbs of BITS bits, 64-bit column accumulators, NO carry counts
+// The engine's multiplier (fe_mul: 8 x 32-bit words) pays one carry count per product because v_mad_u64_u32 has no carry-in: 73 multiply-adds + 72 carry steps + 25
+// others, and a carry step costs the issue time of a multiply-add on this chip.  With limbs narrow enough that a whole column of products fits 64 bits -- 9 x 29 bits:
+// 9 * 2^58 < 2^61.2; 10 x 26 bits: 10 * 2^52 < 2^55.4 -- the carry counts disappear; what comes instead is MORE products (81 / 100 for 64), a shift + mask + move per
+// column to cut the sums back to limbs, and a fold mod p whose constant no longer sits on a limb boundary: 2^(N*BITS) = 2^HI * 2^256 = 2^HI * (2^32 + 977) (mod p) lands
+// as  high_limb * (977 << HI)  on limb j and  high_limb << (32 + HI - BITS)  on limb j + 1: two multiply-adds per high limb (a 64-bit shift-add issues no faster).
+// unsat<29, 9>: 81 + 18 + 2 multiply-adds, ~90 32-bit operations; unsat<26, 10>: 100 + 20 + 2 and ~100.  Inputs and outputs fully normalised (limbs < 2^BITS, value < 2^256,
+// congruent mod p): a lazy form would make field additions cheap but breaks the 9 * 2^58 column bound.  `microbench unsatcheck` compares both with fe_mul on random and
+// extreme operands; `microbench power 203|204 <s>` is the sustained rate for tools/power_ops.sh.
+template <int BITS, int N>
+struct unsat {
+    static constexpr int HI = N * BITS - 256;                       // bits of the limb vector beyond 2^256
+    static constexpr int TOPBITS = 256 - (N - 1) * BITS;            // width of the top limb of a normalised value
+    static constexpr u32 M = (1u << BITS) - 1u, MTOP = (1u << TOPBITS) - 1u;
+    static constexpr u32 C1 = 977u << HI;                           // 2^(N BITS) = C1 + 2^BITS * 2^S1  (mod p)
+    static constexpr int S1 = 32 + HI - BITS;
+    static constexpr int S2 = 32 - BITS;                            // 2^256 = 977 + 2^BITS * 2^S2  (mod p)
+    u32 l[N];
+
+    __device__ __forceinline__ void from_fe(const fe &a)
+    {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int bit = i * BITS, w = bit >> 5, sh = bit & 31;
+            u64 v = a.v[w];
+            if (w + 1 < 8) v |= (u64)a.v[w + 1] << 32;
+            l[i] = (u32)(v >> sh) & (i == N - 1 ? MTOP : M);
+        }
+    }
+    __device__ __forceinline__ void to_fe(fe &r) const
+    {
+#pragma unroll
+        for (int w = 0; w < 8; w++) r.v[w] = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const int bit = i * BITS, w = bit >> 5, sh = bit & 31;
+            const u64 v = (u64)l[i] << sh;
+            r.v[w] |= (u32)v;
+            if (w + 1 < 8) r.v[w + 1] |= (u32)(v >> 32);
+        }
+    }
+    // r = a * b mod p, normalised
+    static __device__ __forceinline__ void mul(unsat &r, const unsat &a, const unsat &b)
+    {
+        u32 c[2 * N];                                               // the 2N limbs of the product
+        u64 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * N - 1; k++) {
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < N) acc += (u64)a.l[i] * b.l[j];    // one v_mad_u64_u32 each: the column (plus the carry it started from) fits 64 bits
+            }
+            c[k] = (u32)acc & M;
+            acc >>= BITS;
+        }
+        c[2 * N - 1] = (u32)acc;                                    // < 2^(2 TOPBITS - BITS + 1)
+        // fold the N high limbs: t[j] = c[j] + C1 h[j] + (h[j-1] << S1), h = c[N ..]; the last high limb's shifted share lands on limb N: t9
+        u64 t[N + 1];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            t[j] = (u64)c[N + j] * C1 + c[j];
+            if (j > 0) t[j] += (u64)c[N + j - 1] << S1;
+        }
+        const u32 t9 = c[2 * N - 1] << S1;                          // limb N once more (tiny): folded below
+        t[0] += (u64)t9 * C1;
+        t[1] += (u64)t9 << S1;
+        // cut back to limbs; what leaves the top limb is a multiple of 2^256 = 977 + (2^S2 << BITS)
+        u64 cr = 0;
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) { const u64 v = t[j] + cr; r.l[j] = (u32)v & M; cr = v >> BITS; }
+        u64 v = t[N - 1] + cr;
+        r.l[N - 1] = (u32)v & MTOP;
+        u64 top = v >> TOPBITS;                                     // < 2^24
+        // top * (2^32 + 977) onto limbs 0 and 1, rippling on (each round's `top` is a single bit at most after the first)
+        while (__builtin_expect(top != 0, 1)) {
+            u64 w0 = (u64)r.l[0] + top * 977u, w1;
+            r.l[0] = (u32)w0 & M;
+            w1 = (u64)r.l[1] + (top << S2) + (w0 >> BITS);
+            r.l[1] = (u32)w1 & M;
+            u64 c2 = w1 >> BITS;
+#pragma unroll
+            for (int j = 2; j < N - 1; j++) { if (__builtin_expect(c2 == 0, 1)) break; const u64 x = (u64)r.l[j] + c2; r.l[j] = (u32)x & M; c2 = x >> BITS; }
+            const u64 x = (u64)r.l[N - 1] + c2;
+            r.l[N - 1] = (u32)x & MTOP;
+            top = x >> TOPBITS;
+        }
+    }
+};
+
 // OP 200: fe_mul (integer, with the fold) ; 201: fe_mul512 only (integer product, no fold) ; 202: dpf_mul512 (FP64 product, no fold)
 template <int OP>
 __global__ void __launch_bounds__(256) mulrate_kernel(u32 *out, int iters, u32 seed)
@@ -337,6 +427,19 @@ __global__ void __launch_bounds__(256) mulrate_kernel(u32 *out, int iters, u32 s
             for (int i = 0; i < 6; i++) b.l[i] = V[i] + V[i + 6];
         }
         r = (u32)a.l[0] ^ (u32)b.l[3];
+    } else if (OP == 203 || OP == 204) {
+        fe a0, b0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { a0.v[i] = seed * 2654435761u + t * 40503u + i; b0.v[i] = a0.v[i] ^ 0x9E3779B9u; }
+        if (OP == 203) {
+            unsat<29, 9> a, b; a.from_fe(a0); b.from_fe(b0);
+            for (int it = 0; it < iters; it++) { unsat<29, 9>::mul(a, a, b); unsat<29, 9>::mul(b, b, a); }
+            r = a.l[0] ^ b.l[3];
+        } else {
+            unsat<26, 10> a, b; a.from_fe(a0); b.from_fe(b0);
+            for (int it = 0; it < iters; it++) { unsat<26, 10>::mul(a, a, b); unsat<26, 10>::mul(b, b, a); }
+            r = a.l[0] ^ b.l[3];
+        }
     } else {
         fe a, b;
 #pragma unroll
@@ -373,6 +476,53 @@ static void sustain_mul(const char *name, double secs, u32 *dout)
         total_ms += ms; n += (double)blocks * threads * iters * 2.0;
     }
     printf("{\"bench\":\"sustain\",\"op\":\"%s\",\"seconds\":%.2f,\"Gmul_per_s\":%.1f}\n", name, total_ms / 1e3, n / (total_ms * 1e-3) / 1e9);
+}
+
+// correctness of the unsaturated multipliers against the engine's fe_mul: chains of dependent products from random and extreme operands, compared canonically
+template <int BITS, int N>
+__global__ void unsat_check_kernel(const fe *a_in, const fe *b_in, unsigned long long *bad, int n, int chain)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    fe a = a_in[t], b = b_in[t];
+    unsat<BITS, N> ua, ub;
+    ua.from_fe(a); ub.from_fe(b);
+    unsigned long long mine = 0;
+    for (int k = 0; k < chain; k++) {
+        fe_mul(a, a, b); unsat<BITS, N>::mul(ua, ua, ub);
+        fe_mul(b, b, a); unsat<BITS, N>::mul(ub, ub, ua);
+        fe x = a, y; ua.to_fe(y);
+        fe_canon(x); fe_canon(y);
+        mine += !fe_eq(x, y);
+        x = b; ub.to_fe(y);
+        fe_canon(x); fe_canon(y);
+        mine += !fe_eq(x, y);
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+static int unsat_check()
+{
+    const int n = 1 << 16, chain = 16;
+    std::vector<fe> a(n), b(n);
+    u64 s = 0x123456789ABCDEFull;
+    auto rnd = [&]() { s += 0x9E3779B97F4A7C15ull; u64 z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return (u32)((z ^ (z >> 31)) >> 16); };
+    const u32 P[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 8; k++) {
+            a[i].v[k] = rnd(); b[i].v[k] = rnd();
+            if (i < 64) { a[i].v[k] = (i & 1) ? P[k] - (k == 0 ? (u32)(i >> 1) : 0u) : 0xFFFFFFFFu; if (i & 2) b[i].v[k] = 0xFFFFFFFFu; }      // p - small, 2^256 - 1: the extremes of the representation
+            if (i >= 64 && i < 128) { a[i].v[k] = k == 0 ? (u32)(i - 63) : 0u; }
+        }
+    fe *da, *db; unsigned long long *dbad, h[2] = {0, 0};
+    CK(hipMalloc(&da, n * sizeof(fe))); CK(hipMalloc(&db, n * sizeof(fe))); CK(hipMalloc(&dbad, 16));
+    CK(hipMemcpy(da, a.data(), n * sizeof(fe), hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * sizeof(fe), hipMemcpyHostToDevice));
+    CK(hipMemset(dbad, 0, 16));
+    hipLaunchKernelGGL((unsat_check_kernel<29, 9>), dim3(n / 256), dim3(256), 0, 0, da, db, dbad, n, chain);
+    hipLaunchKernelGGL((unsat_check_kernel<26, 10>), dim3(n / 256), dim3(256), 0, 0, da, db, dbad + 1, n, chain);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h, dbad, 16, hipMemcpyDeviceToHost));
+    printf("{\"bench\":\"unsatcheck\",\"products_each\":%d,\"mismatches_9x29\":%llu,\"mismatches_10x26\":%llu}\n", n * chain * 2, h[0], h[1]);
+    return (h[0] || h[1]) ? 1 : 0;
 }
 
 // correctness of dpf_mul512 against exact integer arithmetic on the host: 2^16 random operand pairs
@@ -489,12 +639,15 @@ int main(int argc, char **argv)
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "dpfcheck")) return dpf_check() ? 1 : 0;
+    if (argc >= 2 && !strcmp(argv[1], "unsatcheck")) return unsat_check();
     if (argc >= 4 && !strcmp(argv[1], "power")) {
         u32 *dout; CK(hipMalloc(&dout, 256 * 8 * 256 * 4));
         const int op = atoi(argv[2]); const double secs = atof(argv[3]);
         switch (op) {
         case 200: sustain_mul<200>("fe_mul: integer 256x256 product + fold mod p (the engine's multiplier)", secs, dout); break;
         case 201: sustain_mul<201>("fe_mul512: integer 256x256->512 product only", secs, dout); break;
+        case 203: sustain_mul<203>("unsat 9x29: 81 products in 64-bit columns (no carry counts) + fold mod p, normalised in and out", secs, dout); break;
+        case 204: sustain_mul<204>("unsat 10x26: 100 products in 64-bit columns (no carry counts) + fold mod p, normalised in and out", secs, dout); break;
         case 202: sustain_mul<202>("dpf_mul512: FP64 6x48-bit-limb 288x288->576 product only (no fold, no normalisation, no conversion)", secs, dout); break;
         case 105: sustain_gups<2>(secs, 16384, dout); break;       // 32-byte half lines: 2 lanes x 16 B
         case 100: sustain_gups<4>(secs, 16384, dout); break;
