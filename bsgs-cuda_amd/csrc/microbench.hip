@@ -358,6 +358,58 @@ struct unsat {
             if (w + 1 < 8) r.v[w + 1] |= (u32)(v >> 32);
         }
     }
+    // the same product written for the ISA: carries by v_alignbit_b32 (a column sum stays below 2^(32 + BITS), so its carry fits 32 bits), every 64-bit addition as a
+    // multiply-add by an opaque 1 (v_mad_u64_u32: 4.2 cycles; a 64-bit add is two carry steps: 8.2), the shifted share of the fold as a multiply-add by an opaque 2^S1
+    static __device__ __forceinline__ void mul_tuned(unsat &r, const unsat &a, const unsat &b)
+    {
+        u32 one = 1u, sh1 = 1u << S1, c1 = C1;
+        asm volatile("" : "+v"(one), "+v"(sh1), "+v"(c1));           // opaque: the compiler must not turn the multiply-adds into shifts and 64-bit adds
+        u32 c[2 * N];
+        u32 cy = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * N - 1; k++) {
+            u64 acc = cy;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < N) acc = (u64)a.l[i] * b.l[j] + acc;
+            }
+            c[k] = (u32)acc & M;
+            cy = __builtin_amdgcn_alignbit((u32)(acc >> 32), (u32)acc, BITS);
+        }
+        c[2 * N - 1] = cy;
+        u64 t[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            t[j] = (u64)c[N + j] * c1 + c[j];
+            if (j > 0) t[j] = (u64)c[N + j - 1] * sh1 + t[j];
+        }
+        const u32 t9 = c[2 * N - 1] << S1;
+        t[0] = (u64)t9 * c1 + t[0];
+        t[1] = (u64)t9 * sh1 + t[1];
+        u32 cr = 0;
+#pragma unroll
+        for (int j = 0; j < N - 1; j++) {
+            const u64 v = (u64)cr * one + t[j];                      // t[j] < 2^46, cr < 2^17
+            r.l[j] = (u32)v & M;
+            cr = __builtin_amdgcn_alignbit((u32)(v >> 32), (u32)v, BITS);
+        }
+        const u64 v = (u64)cr * one + t[N - 1];
+        r.l[N - 1] = (u32)v & MTOP;
+        u32 top = __builtin_amdgcn_alignbit((u32)(v >> 32), (u32)v, TOPBITS);
+        while (__builtin_expect(top != 0, 1)) {                      // top * (2^32 + 977) onto limbs 0 and 1, rippling on (rarely beyond limb 2)
+            const u64 w0 = (u64)top * 977u + r.l[0];
+            r.l[0] = (u32)w0 & M;
+            const u32 w1 = r.l[1] + (top << S2) + (u32)(w0 >> BITS);  // < 2^BITS + 2^(24 + S2) + 2^6: fits 32 bits (BITS + S2 = 32, top < 2^24 only on the first round)
+            r.l[1] = w1 & M;
+            u32 c2 = w1 >> BITS;
+#pragma unroll
+            for (int j = 2; j < N - 1; j++) { if (__builtin_expect(c2 == 0, 1)) break; const u32 x = r.l[j] + c2; r.l[j] = x & M; c2 = x >> BITS; }
+            const u32 x = r.l[N - 1] + c2;
+            r.l[N - 1] = x & MTOP;
+            top = x >> TOPBITS;
+        }
+    }
     // r = a * b mod p, normalised
     static __device__ __forceinline__ void mul(unsat &r, const unsat &a, const unsat &b)
     {
@@ -427,18 +479,22 @@ __global__ void __launch_bounds__(256) mulrate_kernel(u32 *out, int iters, u32 s
             for (int i = 0; i < 6; i++) b.l[i] = V[i] + V[i + 6];
         }
         r = (u32)a.l[0] ^ (u32)b.l[3];
-    } else if (OP == 203 || OP == 204) {
+    } else if (OP == 203 || OP == 204 || OP == 205) {
         fe a0, b0;
 #pragma unroll
         for (int i = 0; i < 8; i++) { a0.v[i] = seed * 2654435761u + t * 40503u + i; b0.v[i] = a0.v[i] ^ 0x9E3779B9u; }
         if (OP == 203) {
             unsat<29, 9> a, b; a.from_fe(a0); b.from_fe(b0);
+            for (int it = 0; it < iters; it++) { unsat<29, 9>::mul_tuned(a, a, b); unsat<29, 9>::mul_tuned(b, b, a); }
+            r = (a.l[0] ^ b.l[3]) + 0x12000000u;              // (the sink compares with 0x12345678: it must stay REACHABLE for limbs below 2^29 / 2^26, or the loop is dead code)
+        } else if (OP == 205) {
+            unsat<29, 9> a, b; a.from_fe(a0); b.from_fe(b0);
             for (int it = 0; it < iters; it++) { unsat<29, 9>::mul(a, a, b); unsat<29, 9>::mul(b, b, a); }
-            r = a.l[0] ^ b.l[3];
+            r = (a.l[0] ^ b.l[3]) + 0x12000000u;
         } else {
             unsat<26, 10> a, b; a.from_fe(a0); b.from_fe(b0);
-            for (int it = 0; it < iters; it++) { unsat<26, 10>::mul(a, a, b); unsat<26, 10>::mul(b, b, a); }
-            r = a.l[0] ^ b.l[3];
+            for (int it = 0; it < iters; it++) { unsat<26, 10>::mul_tuned(a, a, b); unsat<26, 10>::mul_tuned(b, b, a); }
+            r = (a.l[0] ^ b.l[3]) + 0x12000000u;
         }
     } else {
         fe a, b;
@@ -489,8 +545,8 @@ __global__ void unsat_check_kernel(const fe *a_in, const fe *b_in, unsigned long
     ua.from_fe(a); ub.from_fe(b);
     unsigned long long mine = 0;
     for (int k = 0; k < chain; k++) {
-        fe_mul(a, a, b); unsat<BITS, N>::mul(ua, ua, ub);
-        fe_mul(b, b, a); unsat<BITS, N>::mul(ub, ub, ua);
+        fe_mul(a, a, b); unsat<BITS, N>::mul(ua, ua, ub);                  // the plain form ...
+        fe_mul(b, b, a); unsat<BITS, N>::mul_tuned(ub, ub, ua);            // ... and the one written for the ISA, alternately
         fe x = a, y; ua.to_fe(y);
         fe_canon(x); fe_canon(y);
         mine += !fe_eq(x, y);
@@ -646,8 +702,9 @@ int main(int argc, char **argv)
         switch (op) {
         case 200: sustain_mul<200>("fe_mul: integer 256x256 product + fold mod p (the engine's multiplier)", secs, dout); break;
         case 201: sustain_mul<201>("fe_mul512: integer 256x256->512 product only", secs, dout); break;
-        case 203: sustain_mul<203>("unsat 9x29: 81 products in 64-bit columns (no carry counts) + fold mod p, normalised in and out", secs, dout); break;
-        case 204: sustain_mul<204>("unsat 10x26: 100 products in 64-bit columns (no carry counts) + fold mod p, normalised in and out", secs, dout); break;
+        case 203: sustain_mul<203>("unsat 9x29 (written for the ISA: alignbit carries, multiply-adds for every 64-bit addition): 81 products in 64-bit columns, no carry counts, + fold mod p, normalised in and out", secs, dout); break;
+        case 204: sustain_mul<204>("unsat 10x26 (written for the ISA): 100 products in 64-bit columns, no carry counts, + fold mod p, normalised in and out", secs, dout); break;
+        case 205: sustain_mul<205>("unsat 9x29 (plain C++: 64-bit shifts and additions as the compiler lowers them)", secs, dout); break;
         case 202: sustain_mul<202>("dpf_mul512: FP64 6x48-bit-limb 288x288->576 product only (no fold, no normalisation, no conversion)", secs, dout); break;
         case 105: sustain_gups<2>(secs, 16384, dout); break;       // 32-byte half lines: 2 lanes x 16 B
         case 100: sustain_gups<4>(secs, 16384, dout); break;

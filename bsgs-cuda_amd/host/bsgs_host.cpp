@@ -89,6 +89,7 @@ struct Config {
     uint32_t htsz_arg = 25;                        // what the extended-table entry points take as `htsz`: the exponent, or -- `-htsz` with a fraction, `-buckets` -- the bucket COUNT
     std::string startup = "auto";                  // -startup: how N engines get their replicas -- broadcast | local | allgather | auto (include/bsgs_hip.h BSGS_STARTUP_*)
     std::string transport = "auto";                // -transport: rccl | peer | auto
+    bool w_auto = false;                           // -w auto: the table Tune picks for the range given (tune_plan)
     bool file_search = false;                      // -sf (hidden in the reference too, 1_9_7File.pb:907-918): htCPU looked up in the file instead of RAM; accepted, the resolver keeps it in RAM
 };
 
@@ -120,6 +121,7 @@ static void usage(const Config &c)
            "-startup     Several GPUs: broadcast (GPU 0 holds the table, the others receive it over xGMI), local (every GPU builds / uploads its own),\n"
            "             allgather (extended tables: every GPU builds 1/N of the bucket lines, then all-gather); default: local for extended tables, else broadcast\n"
            "-transport   Several GPUs: rccl | peer (direct peer copies) | auto (RCCL when the GPUs are distinct and librccl loads)\n"
+           "-w auto      The table Tune picks for the range given: the one that minimises table build + worst-case search (a 64-bit range: -w 30 -ext)\n"
            "-buckets     Extended table: the number of buckets itself (any number below 2^32, 128-byte lines), e.g. -w 35 -buckets 1610612736; -htsz 30.585 says the same\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
 }
@@ -141,6 +143,7 @@ static Config parse_args(int argc, char **argv)
         else if (a == "-pke") { c.pke = cut_hex(next()); c.pke_given = true; printf("Range end: 0x%s\n", c.pke.c_str()); }
         else if (a == "-w") {                                   // <=32: 2^value (fractional allowed), else decimal  (1009-1022)
             const std::string v = next();
+            if (v == "auto" || v == "AUTO") { c.w_auto = true; printf("Items number: chosen for the range (Tune)\n"); continue; }
             const double d = atof(v.c_str());
             // the reference switches to decimal above 32; 33..36 are exponents of the extended table here
             if (d <= 36.0) { c.w = (uint64_t)std::pow(2.0, d); printf("Items number set to 2^%s=%llu\n", v.c_str(), (unsigned long long)c.w); }
@@ -706,6 +709,42 @@ static TuneAdvice tune_advice(uint64_t free_bytes)
     a.ext = eh + 3 > 31; a.ext_w_log2 = std::min(eh + 3, 36u); a.ext_htsz = eh;
     return a;
 }
+// Tune for a RANGE.  What a search of 2^range_bits keys costs with w baby steps on n GPUs: the table has to be built (and, in the reference's
+// format, brought to the host: the resolver's htCPU and the two HT files), then at most 2^range_bits / (2w * rate * n) seconds are searched -- a small range wants a small
+// table, a large one the largest that fits.  Rates measured on MI355X: reference-format build 8.2 G points/s, extended build 11 G/s (10 G/s into 128-byte
+// lines), tile kernel 40 G giant-steps/s on 64-byte lines (36 G when the whole job is a launch of < 48 tiles), 33 G on 128-byte lines; 25 GB/s to the host.
+struct TunePlan { double w_log2; uint32_t htsz_arg; bool ext; double build_s, search_s, total_s; };
+static TunePlan tune_plan(uint64_t free_bytes, double range_bits, int n_gpus, uint64_t maxnonce)
+{
+    const double budget = (double)free_bytes - std::min(34.0 * 1073741824.0, 0.5 * (double)free_bytes);     // chain scratch (24 GiB at most; the engine sizes its launches by what is left), giants, the builder's own scratch
+    const double range = std::pow(2.0, range_bits), n = std::max(1, n_gpus);
+    TunePlan best{};
+    best.total_s = 1e300;
+    auto consider = [&](double wl, uint32_t htsz_arg, bool ext, double bytes, double build_rate, double step_rate, double to_host_bytes) {
+        if (bytes > budget) return;
+        const double w = std::pow(2.0, wl);
+        const double tiles = std::ceil(range / (4.0 * (double)maxnonce * w)) + 1.0;              // the tile that holds the end of the range is still searched (1_9_7File.pb:2512-2518)
+        const double rate = tiles / n < 48.0 ? std::min(step_rate, 36e9) : step_rate;
+        TunePlan p{wl, htsz_arg, ext, w / build_rate + to_host_bytes / 25e9, tiles * 2.0 * (double)maxnonce / rate / n, 0.0};
+        p.total_s = p.build_s + p.search_s;
+        if (p.total_s < best.total_s * 0.999) best = p;
+    };
+    for (int k = 20; k <= 31; k++) {                                             // the reference's format: 2^(k-2) buckets (load 4), lines + image on the device, both files on the host
+        const double w = std::pow(2.0, k), b = std::pow(2.0, k - 2);
+        consider(k, (uint32_t)(k - 2), false, 68.0 * b + 4.0 * w, 8.2e9, 40e9, 12.0 * w);
+    }
+    for (int k = 24; k <= 34; k++) consider(k, (uint32_t)(k - 3), true, 64.0 * std::pow(2.0, k - 3) + 0.04 * std::pow(2.0, k), 11e9, k >= 33 ? 39e9 : 40e9, 0.0);      // extended, 64-byte lines, load 8
+    consider(35.0, 1610612736u, true, 128.0 * 1610612736.0 + 5.0 * 1073741824.0, 10e9, 33e9, 0.0);                                                                 // 1.5 * 2^30 lines of 128 bytes
+    if (best.total_s > 1e299) { best = TunePlan{20.0, 18u, false, 0.0, 0.0, 0.0}; }
+    return best;
+}
+static std::string plan_flags(const TunePlan &p)
+{
+    char buf[160];
+    if (p.htsz_arg > 31) snprintf(buf, sizeof buf, "-w %.0f -buckets %u (extended table)", p.w_log2, p.htsz_arg);
+    else snprintf(buf, sizeof buf, "-w %.0f -htsz %u%s", p.w_log2, p.htsz_arg, p.ext ? " -ext" : "");
+    return buf;
+}
 static void tune(int gpu)
 {
     bsgs_dev *dev = nullptr;
@@ -800,6 +839,11 @@ static int selftest(int argc, char **argv)
         } else if (a[i] == "tune" && i + 1 < a.size()) {                      // free bytes -> the MI355X sizing advice (replaces Tune, 1_9_7File.pb:324-431)
             const TuneAdvice t = tune_advice(strtoull(a[++i].c_str(), nullptr, 10));
             printf("tune -w %.2f -htsz %u ext %d -w %u -htsz %u\n", t.w_log2, t.htsz, t.ext ? 1 : 0, t.ext_w_log2, t.ext_htsz);
+        } else if (a[i] == "plan" && i + 3 < a.size()) {                      // free bytes, range bits, GPUs -> the table Tune picks for that range
+            const uint64_t fr = strtoull(a[i + 1].c_str(), nullptr, 10);
+            const TunePlan pl = tune_plan(fr, atof(a[i + 2].c_str()), atoi(a[i + 3].c_str()), 1ull << 24);
+            i += 3;
+            printf("plan %s | w %.2f htsz %u ext %d build %.3f search %.3f total %.3f\n", plan_flags(pl).c_str(), pl.w_log2, pl.htsz_arg, pl.ext ? 1 : 0, pl.build_s, pl.search_s, pl.total_s);
         } else if (a[i] == "checkpoint" && i + 1 < a.size()) {                // next counter, then in-flight counters ("-" = idle GPU): the saved one
             Shared S;
             if (!hs::fe_from_hex(S.glob_key, a[++i])) return 2;
@@ -840,6 +884,38 @@ int main(int argc, char **argv)
     stage("runtime + device discovery");
     for (int g : gpus) tune(g);
     stage("Tune lines (open / close every GPU)");
+    // ---- range (1_9_7File.pb:4887-4943)
+    if (!hs::fe_from_hex(S.start, c.pk) || hs::fe_is_zero(S.start)) die("Start range can`t be zero");
+    printf("START RANGE= %s\n", hs::fe_to_hex(S.start).c_str());
+    {   // the end of range is ALWAYS in force: privkeyend defaults to 1ffffffffffffffff and endrangeflag is set whenever it is
+        // non-zero (1_9_7File.pb:210, 4897-4936); a key outside [pk, pke] ends with "Reached end of space"
+        Scalar e;
+        if (!hs::fe_from_hex(e, c.pke)) die("Invalid range (-pkend) length!!!");
+        if (!hs::fe_is_zero(e)) {
+            if (hs::fe_cmp(e, S.start) <= 0) die(c.pke_given ? "End range should be more than begin range!" : "End range must be more then start range");
+            S.width = hs::sc_sub(e, S.start); S.end_range = true;
+            int bits = 0;
+            for (int l = 3; l >= 0 && !bits; l--) if (S.width.l[l]) bits = 64 * l + 64 - __builtin_clzll(S.width.l[l]);
+            printf("  END RANGE= %s\nWIDTH RANGE= %s = 2^%d\n", hs::fe_to_hex(e).c_str(), hs::fe_to_hex(S.width).c_str(), bits);
+        }
+    }
+    S.start_neg = hs::affine_neg(hs::point_mul(hs::G, S.start));
+    int range_bits = 0;
+    if (S.end_range) for (int l = 3; l >= 0 && !range_bits; l--) if (S.width.l[l]) range_bits = 64 * l + 64 - __builtin_clzll(S.width.l[l]);
+    if (range_bits) {
+        // Tune for THIS range (the reference's Tune, 1_9_7File.pb:324-431, knows the GPU only): the table that minimises build + worst-case search
+        bsgs_dev *dt = nullptr;
+        uint64_t fr = 0, tot = 0;
+        if (bsgs_dev_open(gpus[0], &dt) == BSGS_OK) { bsgs_dev_meminfo(dt, &fr, &tot); bsgs_dev_close(dt); }
+        const TunePlan pl = tune_plan(fr, (double)range_bits, (int)gpus.size(), (uint64_t)c.t * c.b * c.p);
+        printf("Tune for this range (2^%d keys, %zu GPU engine(s)): %s  -> table %.2fs + search at most %.2fs\n", range_bits, gpus.size(), plan_flags(pl).c_str(), pl.build_s, pl.search_s);
+        if (c.w_auto) {
+            Config &cw = S.cfg;
+            cw.w = (uint64_t)std::llround(std::pow(2.0, pl.w_log2)); cw.ext = pl.ext; cw.htsz_arg = pl.htsz_arg;
+            cw.htsz = pl.htsz_arg <= 31 ? pl.htsz_arg : (uint32_t)std::floor(std::log2((double)pl.htsz_arg));
+            printf("-w auto: Items number set to 2^%.2f=%llu, %s\n", pl.w_log2, (unsigned long long)cw.w, pl.ext ? "extended table in GPU memory (no HT files)" : "reference-format HT files");
+        }
+    } else if (c.w_auto) die("-w auto needs a range (-pk / -pke)");
     S.maxnonce = (uint64_t)c.t * c.b * c.p;
     // constants (1_9_7File.pb:4689-4712, 4759-4765)
     const Scalar two_w = hs::sc_from_u128((hs::u128)c.w * 2);
@@ -892,22 +968,6 @@ int main(int argc, char **argv)
     stage("table + giants files (load, or build + save)");
     if (c.onlygen) { flush_writers(); printf("onlygen: files ready\n"); return 0; }
 
-    // ---- range (1_9_7File.pb:4887-4943)
-    if (!hs::fe_from_hex(S.start, c.pk) || hs::fe_is_zero(S.start)) die("Start range can`t be zero");
-    printf("START RANGE= %s\n", hs::fe_to_hex(S.start).c_str());
-    {   // the end of range is ALWAYS in force: privkeyend defaults to 1ffffffffffffffff and endrangeflag is set whenever it is
-        // non-zero (1_9_7File.pb:210, 4897-4936); a key outside [pk, pke] ends with "Reached end of space"
-        Scalar e;
-        if (!hs::fe_from_hex(e, c.pke)) die("Invalid range (-pkend) length!!!");
-        if (!hs::fe_is_zero(e)) {
-            if (hs::fe_cmp(e, S.start) <= 0) die(c.pke_given ? "End range should be more than begin range!" : "End range must be more then start range");
-            S.width = hs::sc_sub(e, S.start); S.end_range = true;
-            int bits = 0;
-            for (int l = 3; l >= 0 && !bits; l--) if (S.width.l[l]) bits = 64 * l + 64 - __builtin_clzll(S.width.l[l]);
-            printf("  END RANGE= %s\nWIDTH RANGE= %s = 2^%d\n", hs::fe_to_hex(e).c_str(), hs::fe_to_hex(S.width).c_str(), bits);
-        }
-    }
-    S.start_neg = hs::affine_neg(hs::point_mul(hs::G, S.start));
 
     // ---- recovery (-wl, 1_9_7File.pb:4634-4686)
     bool recovery = false; int rec_pos = 0; std::string rec_pub, rec_cnt;
@@ -930,11 +990,12 @@ int main(int argc, char **argv)
         while (std::getline(f, line)) { while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back(); if (!line.empty()) pubs.push_back(cut_hex(line)); }
     } else pubs.push_back(c.pub);
 
-    if (c.ext) {
+    std::thread mini_builder;                                           // extended tables: the resolver's own multiples of G, built on the host BEHIND the GPU start-up
+    if (c.ext) mini_builder = std::thread([&S, &c]() {
         const auto t0 = std::chrono::steady_clock::now();
-        S.mini.build(c.w, std::thread::hardware_concurrency());
-        printf("Resolver table: 2^%u multiples of G in %.1fs\n", S.mini.mb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-    }
+        S.mini.build(c.w, std::max(1u, std::thread::hardware_concurrency() / 2));
+        printf("Resolver table: 2^%u multiples of G in %.1fs (behind the start-up)\n", S.mini.mb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    });
     std::vector<bsgs_dev *> devs(gpus.size(), nullptr);
     {
         for (size_t gi = 0; gi < gpus.size(); gi++) devs[gi] = open_dev(gpus[gi]);
@@ -945,7 +1006,8 @@ int main(int argc, char **argv)
     stage("upload, bucket lines, chain scratch, replicas");
     if (!c.joblog.empty()) { S.joblog = fopen(c.joblog.c_str(), "w"); if (!S.joblog) die("Can`t create " + c.joblog); }
     flush_writers();
-    stage("files on disk (written behind the start-up)");
+    if (mini_builder.joinable()) mini_builder.join();
+    stage("files on disk / resolver table (behind the start-up)");
     std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
     std::vector<uint8_t>().swap(g2);
 

@@ -105,6 +105,31 @@ def test_tune_advice_for_mi355x():
         assert w < 3069485951 * 1.005 and 64 * 2**htsz + 4 * 2**htsz + 4 * w < free       # (-w is printed with two decimals)
 
 
+def test_tune_plan_for_a_range():
+    """Tune for a RANGE (the reference's Tune, 1_9_7File.pb:324-431, knows the GPU only): the table that minimises build + worst-case search.
+    A 64-bit range wants a table of 2^30..2^31 points built in GPU memory (no files to bring to the host: 0.3 s all in), an 80-bit range the largest table one
+    GPU holds (-w 35 on 1.5 * 2^30 bucket lines of 128 bytes), a small GPU stays within its memory, more GPUs shorten the search and never shrink the table."""
+    def plan(free, bits, gpus):
+        o = selftest("plan", free, bits, gpus)[0]
+        f = o[o.index("|") + 1:]
+        return {"flags": " ".join(o[1:o.index("|")]), "w": float(f[1]), "htsz": int(f[3]), "ext": f[5] == "1", "build": float(f[7]), "search": float(f[9]), "total": float(f[11])}
+    big = 285 * 10**9
+    p64 = plan(big, 64, 1)
+    assert p64["ext"] and 30 <= p64["w"] <= 31 and p64["total"] < 0.4 and p64["flags"].endswith("-ext")
+    p80 = plan(big, 80, 1)
+    assert p80["w"] == 35 and p80["htsz"] == 1610612736 and "-buckets 1610612736" in p80["flags"] and p80["search"] < 600
+    p120 = plan(big, 120, 8)
+    assert p120["w"] == 35 and abs(p120["search"] / plan(big, 120, 1)["search"] - 1 / 8) < 1e-3
+    small = plan(25 * 10**9, 64, 1)
+    assert small["w"] <= 30 and 64 * 2 ** small["htsz"] < 25e9
+    tiny = plan(8 * 10**9, 80, 1)
+    assert tiny["w"] <= 29 and 64 * 2 ** tiny["htsz"] < 8e9
+    # monotone: a larger range never gets a smaller table; and every plan's total is its two parts
+    ws = [plan(big, b, 1) for b in (40, 48, 56, 64, 72, 80, 100)]
+    assert all(a["w"] <= b["w"] for a, b in zip(ws, ws[1:]))
+    assert all(abs(q["build"] + q["search"] - q["total"]) < 2e-3 * max(1.0, q["total"]) for q in ws)
+
+
 def test_checkpoint_is_the_minimum_in_flight_counter():
     """saveCurentCNT (1_9_7File.pb:3897-3931): the saved counter is the smallest one any GPU has not finished, or the
     dispenser's next counter when all GPUs are idle"""
