@@ -162,7 +162,9 @@ struct KeyGen {
     DevBuf chainb, helperb, basesb, gtab, status;
     static void geometry(uint64_t w, uint32_t &T, uint32_t &pi)
     {
-        pi = w >= (1ull << 26) ? 1024 : 256;                        // points per inversion (279 multiplications per block of four waves ... per thread here: 270)
+        // points per inversion (270 multiplications per thread): 1024 for the tables that take seconds to build; below 2^31 points the build is a tenth of a second of
+        // arithmetic and what counts is the scratch it allocates (32 bytes per point of a chunk: 8 GiB at 1024, 2 GiB at 256 -- the driver clears what it hands out at 45 GB/s)
+        pi = w >= (1ull << 31) ? 1024 : 256;
         uint64_t t = 256;
         while (t < (1u << 18) && t * pi < w) t *= 2;                // 2^18 threads = four waves per SIMD on 256 CUs; fewer for small tables
         T = (uint32_t)t;

@@ -506,10 +506,13 @@ static hipError_t lines_malloc_chunks(bsgs_dev *d, PieceGrader &G, void **out, s
     // the reserve for the chain scratch: group-0 chunks that the lines did not need, as mapped pieces; everything else goes back
     float lo = 1e30f, hi = 0.f;
     size_t released = 0;
+    // how much is held back for the chain scratch: 24 chunks (96 GiB) while memory is plentiful -- the scratch is picked from them by grade --, 8 chunks (the 24 GiB of a full
+    // launch + two) when the table took most of the GPU (-w 35: 48 of 66 chunks): everything held back is invisible to the table builder, which runs next and needs 8 GiB itself
+    const size_t reserve_cap = all.size() - need >= 30 ? 24 : 8;
     for (size_t k = 0; k < all.size(); k++) {
         if (used[k]) continue;
         C &c = all[k];
-        if (c.g <= 0.93f * top && d->group0_reserve.size() < 24) {
+        if (c.g <= 0.93f * top && d->group0_reserve.size() < reserve_cap) {
             vm_register(c.va, chunk, chunk, {c.h});
             d->group0_reserve.push_back(c.va);
             lo = std::min(lo, c.g); hi = std::max(hi, c.g);

@@ -20,7 +20,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdarg>
 #include <deque>
+#include <memory>
+#include <unistd.h>
 #include <functional>
 #include <fstream>
 #include <mutex>
@@ -89,6 +92,7 @@ struct Config {
     uint32_t htsz_arg = 25;                        // what the extended-table entry points take as `htsz`: the exponent, or -- `-htsz` with a fraction, `-buckets` -- the bucket COUNT
     std::string startup = "auto";                  // -startup: how N engines get their replicas -- broadcast | local | allgather | auto (include/bsgs_hip.h BSGS_STARTUP_*)
     std::string transport = "auto";                // -transport: rccl | peer | auto
+    int lanes = -1;                                // -lanes: jobs (public keys of -infile) searched side by side, each on its own engine per GPU; -1 = automatic (2 for short jobs)
     bool w_auto = false;                           // -w auto: the table Tune picks for the range given (tune_plan)
     bool file_search = false;                      // -sf (hidden in the reference too, 1_9_7File.pb:907-918): htCPU looked up in the file instead of RAM; accepted, the resolver keeps it in RAM
 };
@@ -121,6 +125,7 @@ static void usage(const Config &c)
            "-startup     Several GPUs: broadcast (GPU 0 holds the table, the others receive it over xGMI), local (every GPU builds / uploads its own),\n"
            "             allgather (extended tables: every GPU builds 1/N of the bucket lines, then all-gather); default: local for extended tables, else broadcast\n"
            "-transport   Several GPUs: rccl | peer (direct peer copies) | auto (RCCL when the GPUs are distinct and librccl loads)\n"
+           "-lanes       -infile: public keys searched side by side, each on an engine of its own per GPU (default: 2 when a job is only a launch or two long, else 1)\n"
            "-w auto      The table Tune picks for the range given: the one that minimises table build + worst-case search (a 64-bit range: -w 30 -ext)\n"
            "-buckets     Extended table: the number of buckets itself (any number below 2^32, 128-byte lines), e.g. -w 35 -buckets 1610612736; -htsz 30.585 says the same\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
@@ -160,6 +165,7 @@ static Config parse_args(int argc, char **argv)
         }
         else if (a == "-buckets") { c.htsz_arg = (uint32_t)strtoull(next().c_str(), nullptr, 10); c.htsz = 0; while ((2ull << c.htsz) <= c.htsz_arg) c.htsz++; printf("HT size set to %u buckets (extended table)\n", c.htsz_arg); }
         else if (a == "-sf") { c.file_search = atoi(next().c_str()) != 0; printf(c.file_search ? "Search in file\n" : "Search in RAM\n"); }
+        else if (a == "-lanes") { c.lanes = atoi(next().c_str()); if (c.lanes < 1 || c.lanes > 4) die("-lanes 1..4"); }
         else if (a == "-startup") { c.startup = next(); for (auto &ch : c.startup) ch = (char)tolower(ch); }
         else if (a == "-transport") { c.transport = next(); for (auto &ch : c.transport) ch = (char)tolower(ch); }
         else if (a == "-infile") { c.infile = next(); printf("Will be used file: %s\n", c.infile.c_str()); }
@@ -234,6 +240,11 @@ struct MiniBsgs {
     std::vector<uint64_t> find(const Affine &T, uint64_t w) const;     // every b' in [1, w] with x(b'G) = x(T)
 };
 
+// what every job of a run reads and nobody writes once the start-up is over: the resolver's tables
+struct Tables {
+    std::vector<uint8_t> htcpu;
+    MiniBsgs mini;                                // extended tables: the resolver's own small BSGS instead of htCPU
+};
 struct Tile { Scalar key; uint64_t index; };          // counter and dispenser index of a tile: centre = walk_p0 + index * PUBADDBIG
 struct PendingHit { uint32_t code, idx; Tile tile; };
 
@@ -242,6 +253,7 @@ struct Shared {
     uint64_t maxnonce = 0;
     double job_tiles = 0.0;                        // tiles in the range of the current job (0 = unbounded / unknown), and the engines that share it
     int ngpus = 1;
+    uint32_t batch_hint = 0;                       // short jobs: tiles per batch (each batch waits for its checker); 0 = a launch per batch
     Scalar center_big, gstep, start, width;      // p*w ; 4*maxnonce*w ; -pk ; pke-pk
     bool end_range = false, past_end = false;
     Affine addpubg, center, pubadd, start_neg;   // -(2w)G ; -(p*w)G ; -(gstep)G ; -(start)G
@@ -266,8 +278,7 @@ struct Shared {
     std::vector<bool> inflight_valid;
     Scalar winkey;
     bool found = false;
-    std::vector<uint8_t> htcpu;
-    MiniBsgs mini;                                // extended tables: the resolver's own small BSGS instead of htCPU
+    Tables *tab = nullptr;
     int listpos = 1;
     std::string mainpub_hex;
 };
@@ -423,10 +434,10 @@ static bool resolve_hit(const Shared &S, const PendingHit &hit, Scalar &key_out)
         if (T.inf) return false;
     }
     std::vector<uint64_t> babies;                 // b' with x(b'G) = x(T) as far as the table knows
-    if (S.cfg.ext) babies = S.mini.find(T, S.cfg.w);
+    if (S.cfg.ext) babies = S.tab->mini.find(T, S.cfg.w);
     else {
         uint32_t pos[64];
-        int np = htcpu_lookup(S.htcpu, 1ull << S.cfg.htsz, T.x.l[0], pos, 64);
+        int np = htcpu_lookup(S.tab->htcpu, 1ull << S.cfg.htsz, T.x.l[0], pos, 64);
         for (int q = 0; q < std::min(np, 64); q++) babies.push_back((uint64_t)pos[q] + 1);
     }
     for (uint64_t bprime : babies) {
@@ -631,7 +642,8 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
     // hit (1_9_7File.pb:2442-2523) -- so such a job is dealt in about six batches per GPU (not below 16 tiles: the narrow batchings keep small launches at
     // 36-38 G): with the key anywhere in the range 0.6 of the work is done on average instead of all of it.
     size_t batch = tpl;
-    if (S->job_tiles && S->job_tiles < 4.0 * tpl * S->ngpus) batch = (size_t)std::min<double>(tpl, std::max(16.0, std::ceil(S->job_tiles / (6.0 * S->ngpus))));
+    const bool wait_for_checker = S->batch_hint != 0;
+    if (S->batch_hint) batch = std::min<size_t>(S->batch_hint, tpl);
     std::vector<Tile> tiles;
     std::vector<uint8_t> centres;
     std::vector<bsgs_hit_ex> hits(65536);
@@ -677,7 +689,7 @@ static void gpu_thread(Shared *S, int gpu, int slot, bsgs_dev *dev)
         S->tiles_done += n;
         // a short job (batches smaller than a launch: see above) does not run ahead of its checker: the next batch is dispensed once this one's hits are resolved
         // (microseconds each with the htCPU table), so that the batch that holds the key is the last one
-        if (batch < tpl) while (!S->quit.load() && S->hits_checked.load() < S->hits_pushed.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (wait_for_checker) while (!S->quit.load() && S->hits_checked.load() < S->hits_pushed.load()) std::this_thread::sleep_for(std::chrono::microseconds(20));
         {
             std::lock_guard<std::mutex> lk(S->inflight_mutex);
             S->inflight_valid[slot] = false;
@@ -865,6 +877,8 @@ int main(int argc, char **argv)
     if (argc >= 2 && std::string(argv[1]) == "-selftest") return selftest(argc, argv);
     printf("BSGS MI355X (drop-in for bsgscudaHT 1.9.7-file0) on %s\n", bsgs_version());
     Shared S;
+    Tables tables;
+    S.tab = &tables;
     S.cfg = parse_args(argc, argv);
     const Config &c = S.cfg;
     // "[startup] <stage> <seconds>" lines: where the time before the first tile goes (bench.py's cold_time_to_solve_s reads them)
@@ -943,13 +957,13 @@ int main(int argc, char **argv)
     bsgs_dev *d0 = nullptr;
     auto dev0 = [&]() { if (!d0) CK(bsgs_dev_open(gpus[0], &d0)); return d0; };
     if (c.ext) printf("Extended table: %llu items, built in GPU memory at start-up (no HT files)\n", (unsigned long long)c.w);
-    else if (read_file(f_gpu, htgpu, gpu_bytes) && read_file(f_cpu, S.htcpu, cpu_bytes)) printf("Both HT files exist\n");
+    else if (read_file(f_gpu, htgpu, gpu_bytes) && read_file(f_cpu, tables.htcpu, cpu_bytes)) printf("Both HT files exist\n");
     else {
         printf("Generate HT with %llu items on the GPU\n", (unsigned long long)c.w);
         const auto t0 = std::chrono::steady_clock::now();
-        htgpu.resize(gpu_bytes); S.htcpu.resize(cpu_bytes);
-        CK(bsgs_build_baby_tables(dev0(), c.w, c.htsz, htgpu.data(), S.htcpu.data(), BSGS_NO_INSTALL));
-        writers.emplace_back([&]() { write_file(f_cpu, S.htcpu.data(), cpu_bytes); });
+        htgpu.resize(gpu_bytes); tables.htcpu.resize(cpu_bytes);
+        CK(bsgs_build_baby_tables(dev0(), c.w, c.htsz, htgpu.data(), tables.htcpu.data(), BSGS_NO_INSTALL));
+        writers.emplace_back([&]() { write_file(f_cpu, tables.htcpu.data(), cpu_bytes); });
         writers.emplace_back([&]() { write_file(f_gpu, htgpu.data(), gpu_bytes); });
         printf("Done in %.1fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
@@ -991,14 +1005,37 @@ int main(int argc, char **argv)
     } else pubs.push_back(c.pub);
 
     std::thread mini_builder;                                           // extended tables: the resolver's own multiples of G, built on the host BEHIND the GPU start-up
-    if (c.ext) mini_builder = std::thread([&S, &c]() {
+    if (c.ext) mini_builder = std::thread([&tables, &c]() {
         const auto t0 = std::chrono::steady_clock::now();
-        S.mini.build(c.w, std::max(1u, std::thread::hardware_concurrency() / 2));
-        printf("Resolver table: 2^%u multiples of G in %.1fs (behind the start-up)\n", S.mini.mb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        tables.mini.build(c.w, std::max(1u, std::thread::hardware_concurrency() / 2));
+        printf("Resolver table: 2^%u multiples of G in %.1fs (behind the start-up)\n", tables.mini.mb, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     });
+    // ---- how long a job is, in tiles (width / gstep): a job that is only a launch or two long (BASELINE config 4: a 64-bit range at -w 30 is 129 tiles) is dealt in small
+    // batches that wait for their checker -- the reference, one tile per launch, stops at the hit (1_9_7File.pb:2442-2523); a full launch would always run to its end --,
+    // its engines take scratch for such batches only, and with several keys to search two jobs run side by side (lanes)
+    double job_tiles = 0.0;
+    {
+        auto as_double = [](const Scalar &v) { double r = 0.0; for (int l = 3; l >= 0; l--) r = r * 18446744073709551616.0 + (double)v.l[l]; return r; };
+        job_tiles = S.end_range ? as_double(S.width) / as_double(S.gstep) + 1.0 : 0.0;
+    }
+    const double tpl_est = std::min(1024.0, std::max(48.0, (double)(192ull << 24) / (double)S.maxnonce));       // the engine's launch size at this geometry, memory permitting
+    const bool short_job = job_tiles > 0.0 && job_tiles < 4.0 * tpl_est * (double)gpus.size();
+    const size_t todo = pubs.size() - (recovery && rec_pos >= 1 && (size_t)rec_pos <= pubs.size() ? (size_t)rec_pos - 1 : 0);
+    size_t lanes = 1;
+    if (c.lanes > 0) lanes = (size_t)c.lanes;
+    else if (short_job && todo >= 4 && !c.ext && c.joblog.empty()) lanes = 2;
+    lanes = std::max<size_t>(1, std::min(lanes, todo));
+    if (short_job) {
+        // about six batches per GPU and job (ten with two lanes: the other lane's launch hides this one's boundaries), not below 16 (8) tiles: the narrow batchings keep
+        // small launches at 35-38 G, and with the key anywhere in the range 0.55-0.6 of the tiles are searched on average instead of all of them
+        S.batch_hint = (uint32_t)std::min(tpl_est, std::max(lanes > 1 ? 8.0 : 16.0, std::ceil(job_tiles / ((lanes > 1 ? 10.0 : 6.0) * (double)gpus.size()))));
+        printf("Short jobs (%.0f tiles each): dealt in batches of %u tiles%s\n", job_tiles, S.batch_hint, lanes > 1 ? ", two public keys searched side by side (an engine each per GPU)" : "");
+    }
+    if (lanes > 1) { const std::vector<int> base = gpus; for (size_t l = 1; l < lanes; l++) gpus.insert(gpus.end(), base.begin(), base.end()); }
     std::vector<bsgs_dev *> devs(gpus.size(), nullptr);
     {
         for (size_t gi = 0; gi < gpus.size(); gi++) devs[gi] = open_dev(gpus[gi]);
+        if (S.batch_hint) for (bsgs_dev *d : devs) CK(bsgs_set_tiles_per_launch(d, S.batch_hint));     // scratch (and its placement) for the batches this run will launch, not for 192 tiles
         load_engines(S, gpus, devs, htgpu, g2);
         if (devs.size() > 1 && c.verify_replicas) verify_replicas(gpus, devs);
         if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }
@@ -1011,104 +1048,167 @@ int main(int argc, char **argv)
     std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
     std::vector<uint8_t>().swap(g2);
 
-    int finditems = 0;
-    bool tuned = false;
-    for (size_t li = 0; li < pubs.size(); li++) {
-        S.listpos = (int)li + 1;
-        if (recovery && S.listpos != rec_pos) continue;
-        if (!hs::parse_pubkey(S.realpub, pubs[li]) || !hs::on_curve(S.realpub)) die("Invalid Public Key (-pb) length!!!");
-        S.mainpub_hex = hs::fe_to_hex(S.realpub.x) + hs::fe_to_hex(S.realpub.y);
-        if (recovery && S.mainpub_hex != rec_pub) die("Find position but the keys are different");
-        printf("\nFindpubkey  : %s\n", hs::compress_pubkey(S.realpub).c_str());
-        S.findpub = hs::point_add(S.realpub, S.start_neg);             // 1_9_7File.pb:5042
-        printf("Searchpubkey: %s\n", hs::compress_pubkey(S.findpub).c_str());
-        // dispenser seed (1_9_7File.pb:5046-5064)
-        S.glob_key = hs::fe_from_u64(1);
-        if (recovery) { if (!hs::fe_from_hex(S.glob_key, rec_cnt)) die("bad counter"); recovery = false; }
-        S.glob_index = 0;
-        S.walk_p0 = hs::point_add(hs::point_add(S.findpub, hs::affine_neg(hs::point_mul(hs::G, S.glob_key))), S.center);
-        if (!c.host_centres) {
-            if (S.walk_p0.inf) die("the public key equals (counter + p*w)*G: the first tile centre is the point at infinity");
-            uint8_t p0[64], st[64];
-            hs::affine_to_le(S.walk_p0, p0, p0 + 32); hs::affine_to_le(S.pubadd, st, st + 32);
-            for (bsgs_dev *d : devs) CK(bsgs_set_walk(d, p0, st));      // from here on the host only advances the counter
-            if (c.tune && !tuned) {
-                // once per run: the launch time depends on which physical memory the driver handed out for the chain scratch and the
-                // bucket lines; try a few placements on every GPU (in parallel) and keep the fastest
-                tuned = true;
-                std::vector<std::array<float, 7>> res(devs.size());
-                std::vector<int> rcs(devs.size(), 0);
-                std::vector<std::string> why(devs.size());
-                std::vector<std::thread> tt;
-                for (size_t gi = 0; gi < devs.size(); gi++) tt.emplace_back([&, gi]() {
-                    uint32_t kept[2] = {0, 0};
-                    rcs[gi] = bsgs_tune_placement(devs[gi], 3, res[gi].data(), kept, &res[gi][6]);
-                    if (rcs[gi]) why[gi] = bsgs_last_error();           // the error text is per thread
-                });
-                for (auto &t : tt) t.join();
-                for (size_t gi = 0; gi < devs.size(); gi++) {
-                    if (rcs[gi]) { printf("GPU #%d: placement tuning skipped (%s)\n", gpus[gi], why[gi].c_str()); continue; }
-                    printf("GPU #%d: placement tuned, %.1f -> %.1f ms per launch\n", gpus[gi], res[gi][0], res[gi][6]);
-                }
-            }
-        }
-        S.past_end = false;
-        {   // width / gstep as floating point: how many tiles the range is long (the batches of a short job are sized by it: gpu_thread)
-            auto as_double = [](const Scalar &v) { double r = 0.0; for (int l = 3; l >= 0; l--) r = r * 18446744073709551616.0 + (double)v.l[l]; return r; };
-            S.job_tiles = S.end_range ? as_double(S.width) / as_double(S.gstep) + 1.0 : 0.0;
-            S.ngpus = (int)gpus.size();
-        }
-        S.quit = false; S.all_done = false; S.found = false; S.gpus_finished = 0; S.steps_done = 0; S.tiles_done = 0; S.hits_checked = 0; S.hits_pushed = 0; S.checker_ns = 0;
-        const auto t0 = std::chrono::steady_clock::now();
-        Scalar one = hs::fe_from_u64(1), two = hs::fe_from_u64(2);
-        Scalar trivial;                                                 // keys 1 and 2 are answered without search (5069-5107)
-        bool is_trivial = false;
-        for (const Scalar &k : {one, two}) { const Affine q = hs::point_mul(hs::G, k); if (hs::fe_equal(q.x, S.realpub.x) && hs::fe_equal(q.y, S.realpub.y)) { trivial = k; is_trivial = true; } }
-        if (!is_trivial) {
-            const unsigned nchk = c.ext ? std::max(2u, std::min(16u, std::thread::hardware_concurrency() / 4)) : 1u;   // false positives cost a small BSGS each
-            std::vector<std::thread> chk;
-            for (unsigned q = 0; q < nchk; q++) chk.emplace_back(checker_thread, &S);
-            std::vector<std::thread> th;
-            S.inflight.assign(gpus.size(), hs::fe_from_u64(0)); S.inflight_valid.assign(gpus.size(), false);
-            for (size_t gi = 0; gi < gpus.size(); gi++) th.emplace_back(gpu_thread, &S, gpus[gi], (int)gi, devs[gi]);
-            auto last_save = std::chrono::steady_clock::now();
-            uint64_t last_steps = 0; auto last_t = t0;
-            while (S.gpus_finished.load() < (int)gpus.size()) {
-                { std::unique_lock<std::mutex> lk(S.done_mutex); S.done_cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return S.gpus_finished.load() >= (int)gpus.size(); }); }
-                const auto now = std::chrono::steady_clock::now();
-                if (std::chrono::duration<double>(now - last_t).count() >= 2.0) {       // progress line 5119-5142
-                    const uint64_t st = S.steps_done.load();
-                    const double rate = (st - last_steps) / std::chrono::duration<double>(now - last_t).count();
-                    Scalar cnt; { std::lock_guard<std::mutex> lk(S.job_mutex); cnt = S.glob_key; }
-                    printf("\rCnt:%s [%d] = %.0f MKeys/s x2^%.2f=2^%.2f   ", hs::fe_to_hex(cnt).c_str() + 40, (int)gpus.size(), rate / 1048576.0,
-                           std::log2(2.0 * c.w), rate > 0 ? std::log2(rate * 2.0 * c.w) : 0.0);
-                    fflush(stdout);
-                    last_steps = st; last_t = now;
-                }
-                if (std::chrono::duration<double>(now - last_save).count() >= c.wt || S.joblog) { save_checkpoint(S); last_save = now; }
-            }
-            for (auto &x : th) x.join();
-            // drain the checker queue, then stop it
-            for (;;) { { std::lock_guard<std::mutex> lk(S.chk_mutex); if (S.checker.empty()) break; } if (S.quit.load()) break; std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
-            S.all_done = true; S.chk_cv.notify_all();
-            for (auto &x : chk) x.join();
-        } else { S.winkey = trivial; S.found = true; }
-        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (S.found) {                                                  // win.txt 1_9_7File.pb:5146-5160
-            const std::string head = "KEY[" + std::to_string(S.listpos) + "]: ";
-            const std::string l1 = head + "0x" + hs::fe_to_hex(S.winkey);
-            const std::string l2 = std::string(head.size() - 5, ' ') + "Pub: " + hs::compress_pubkey(S.realpub);
-            printf("\n****************************\n%s\n%s\n****************************\n", l1.c_str(), l2.c_str());
-            std::ofstream f(c.dir + "/win.txt", std::ios::app | std::ios::binary);
-            f << l1 << "\r\n" << l2 << "\r\n";
-            finditems++;
-        } else printf("\nReached end of space\n");
-        printf("Job time %.2fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)S.tiles_done.load(), (double)S.steps_done.load());
-        printf("Checker: %llu hits resolved in %.3fs of CPU time (%.2f%% of one core)\n", (unsigned long long)S.hits_checked.load(), S.checker_ns.load() * 1e-9,
-               secs > 0 ? 100.0 * S.checker_ns.load() * 1e-9 / secs : 0.0);
+    // ---- the jobs: one public key after the other (1_9_7File.pb:4995-5168) -- or, when a job is only a launch or two long (BASELINE config 4: 1000 keys over a 64-bit
+    // range), `lanes` of them side by side, each on an engine of its own per GPU: while one job waits for its checker, dispenses, or parses the next key, the other's
+    // launch keeps the GPU busy, and no tile is searched on speculation.  win.txt and the console keep the list order; currentwork.txt describes the OLDEST job in flight.
+    const size_t G = gpus.size() / lanes;                             // engines per lane
+    std::vector<std::unique_ptr<Shared>> lane_state;
+    for (size_t l = 0; l < lanes; l++) {
+        std::unique_ptr<Shared> J(new Shared());
+        J->cfg = S.cfg; J->maxnonce = S.maxnonce; J->center_big = S.center_big; J->gstep = S.gstep; J->start = S.start; J->width = S.width; J->end_range = S.end_range;
+        J->addpubg = S.addpubg; J->center = S.center; J->pubadd = S.pubadd; J->start_neg = S.start_neg; J->tab = S.tab; J->joblog = l == 0 ? S.joblog : nullptr; J->batch_hint = S.batch_hint;
+        lane_state.push_back(std::move(J));
     }
-    for (bsgs_dev *d : devs) bsgs_dev_close(d);
+    struct JobOut { bool done = false, found = false; std::string text, win; };
+    std::vector<JobOut> outs(pubs.size());
+    std::mutex out_mutex;
+    size_t next_emit = 0, next_job = 0;
+    int finditems = 0;
+    std::vector<int> lane_listpos(lanes, 0);                          // list position each lane works on (0 = idle): the checkpoint belongs to the smallest
+    std::mutex lane_mutex;
+    const bool live = lanes == 1;                                     // one lane: every line appears as it happens; several: a job's lines are printed when its turn in the list comes
+    auto emit = [&]() {                                               // under out_mutex: print / append to win.txt everything that is complete, in list order
+        while (next_emit < outs.size() && outs[next_emit].done) {
+            JobOut &o = outs[next_emit];
+            if (!live) fputs(o.text.c_str(), stdout);
+            if (o.found) {
+                std::ofstream f(c.dir + "/win.txt", std::ios::app | std::ios::binary);
+                f << o.win;
+                finditems++;
+            }
+            o.text.clear();
+            next_emit++;
+        }
+        fflush(stdout);
+    };
+    bool tuned = false;
+    auto run_lane = [&](size_t l) {
+        Shared &J = *lane_state[l];
+        const std::vector<int> lgpus(gpus.begin() + l * G, gpus.begin() + (l + 1) * G);
+        const std::vector<bsgs_dev *> ldevs(devs.begin() + l * G, devs.begin() + (l + 1) * G);
+        for (;;) {
+            size_t li;
+            bool resumed = false;
+            {
+                std::lock_guard<std::mutex> lk(lane_mutex);
+                while (next_job < pubs.size() && recovery && (int)next_job + 1 != rec_pos) { outs[next_job].done = true; next_job++; }      // -wl: everything before the saved position is skipped
+                if (next_job >= pubs.size()) { lane_listpos[l] = 0; break; }
+                li = next_job++;
+                lane_listpos[l] = (int)li + 1;
+                if (recovery) { resumed = true; recovery = false; }       // this is the saved position: it resumes from the saved counter, everything after it starts fresh
+            }
+            JobOut &o = outs[li];
+            auto say = [&](const char *fmt, ...) {
+                char buf[1024];
+                va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+                if (live) { fputs(buf, stdout); fflush(stdout); } else o.text += buf;
+            };
+            J.listpos = (int)li + 1;
+            if (!hs::parse_pubkey(J.realpub, pubs[li]) || !hs::on_curve(J.realpub)) die("Invalid Public Key (-pb) length!!!");
+            J.mainpub_hex = hs::fe_to_hex(J.realpub.x) + hs::fe_to_hex(J.realpub.y);
+            if (resumed && J.mainpub_hex != rec_pub) die("Find position but the keys are different");
+            say("\nFindpubkey  : %s\n", hs::compress_pubkey(J.realpub).c_str());
+            J.findpub = hs::point_add(J.realpub, J.start_neg);             // 1_9_7File.pb:5042
+            say("Searchpubkey: %s\n", hs::compress_pubkey(J.findpub).c_str());
+            // dispenser seed (1_9_7File.pb:5046-5064)
+            J.glob_key = hs::fe_from_u64(1);
+            if (resumed && !hs::fe_from_hex(J.glob_key, rec_cnt)) die("bad counter");
+            J.glob_index = 0;
+            J.walk_p0 = hs::point_add(hs::point_add(J.findpub, hs::affine_neg(hs::point_mul(hs::G, J.glob_key))), J.center);
+            if (!c.host_centres) {
+                if (J.walk_p0.inf) die("the public key equals (counter + p*w)*G: the first tile centre is the point at infinity");
+                uint8_t p0[64], st[64];
+                hs::affine_to_le(J.walk_p0, p0, p0 + 32); hs::affine_to_le(J.pubadd, st, st + 32);
+                for (bsgs_dev *d : ldevs) CK(bsgs_set_walk(d, p0, st));      // from here on the host only advances the counter
+                if (c.tune && !tuned && l == 0) {
+                    // once per run: the launch time depends on which physical memory the driver handed out for the chain scratch and the
+                    // bucket lines; try a few placements on every GPU (in parallel) and keep the fastest
+                    tuned = true;
+                    std::vector<std::array<float, 7>> res(ldevs.size());
+                    std::vector<int> rcs(ldevs.size(), 0);
+                    std::vector<std::string> why(ldevs.size());
+                    std::vector<std::thread> tt;
+                    for (size_t gi = 0; gi < ldevs.size(); gi++) tt.emplace_back([&, gi]() {
+                        uint32_t kept[2] = {0, 0};
+                        rcs[gi] = bsgs_tune_placement(ldevs[gi], 3, res[gi].data(), kept, &res[gi][6]);
+                        if (rcs[gi]) why[gi] = bsgs_last_error();           // the error text is per thread
+                    });
+                    for (auto &t : tt) t.join();
+                    for (size_t gi = 0; gi < ldevs.size(); gi++) {
+                        if (rcs[gi]) { say("GPU #%d: placement tuning skipped (%s)\n", lgpus[gi], why[gi].c_str()); continue; }
+                        say("GPU #%d: placement tuned, %.1f -> %.1f ms per launch\n", lgpus[gi], res[gi][0], res[gi][6]);
+                    }
+                }
+            }
+            J.past_end = false;
+            J.job_tiles = job_tiles; J.ngpus = (int)G;
+            J.quit = false; J.all_done = false; J.found = false; J.gpus_finished = 0; J.steps_done = 0; J.tiles_done = 0; J.hits_checked = 0; J.hits_pushed = 0; J.checker_ns = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            Scalar one = hs::fe_from_u64(1), two = hs::fe_from_u64(2);
+            Scalar trivial;                                                 // keys 1 and 2 are answered without search (5069-5107)
+            bool is_trivial = false;
+            for (const Scalar &k : {one, two}) { const Affine q = hs::point_mul(hs::G, k); if (hs::fe_equal(q.x, J.realpub.x) && hs::fe_equal(q.y, J.realpub.y)) { trivial = k; is_trivial = true; } }
+            if (!is_trivial) {
+                const unsigned nchk = c.ext ? std::max(2u, std::min(16u, std::thread::hardware_concurrency() / 4)) : 1u;   // false positives cost a small BSGS each
+                std::vector<std::thread> chk;
+                for (unsigned q = 0; q < nchk; q++) chk.emplace_back(checker_thread, &J);
+                std::vector<std::thread> th;
+                J.inflight.assign(G, hs::fe_from_u64(0)); J.inflight_valid.assign(G, false);
+                for (size_t gi = 0; gi < G; gi++) th.emplace_back(gpu_thread, &J, lgpus[gi], (int)gi, ldevs[gi]);
+                auto last_save = std::chrono::steady_clock::now();
+                uint64_t last_steps = 0; auto last_t = t0;
+                while (J.gpus_finished.load() < (int)G) {
+                    { std::unique_lock<std::mutex> lk(J.done_mutex); J.done_cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return J.gpus_finished.load() >= (int)G; }); }
+                    const auto now = std::chrono::steady_clock::now();
+                    if (live && std::chrono::duration<double>(now - last_t).count() >= 2.0) {       // progress line 5119-5142
+                        const uint64_t st = J.steps_done.load();
+                        const double rate = (st - last_steps) / std::chrono::duration<double>(now - last_t).count();
+                        Scalar cnt; { std::lock_guard<std::mutex> lk(J.job_mutex); cnt = J.glob_key; }
+                        printf("\rCnt:%s [%d] = %.0f MKeys/s x2^%.2f=2^%.2f   ", hs::fe_to_hex(cnt).c_str() + 40, (int)G, rate / 1048576.0,
+                               std::log2(2.0 * c.w), rate > 0 ? std::log2(rate * 2.0 * c.w) : 0.0);
+                        fflush(stdout);
+                        last_steps = st; last_t = now;
+                    }
+                    if (std::chrono::duration<double>(now - last_save).count() >= c.wt || J.joblog) {
+                        bool oldest = true;                                 // currentwork.txt: the oldest job in flight (a restart re-does the younger ones from their start)
+                        { std::lock_guard<std::mutex> lk(lane_mutex); for (int lp : lane_listpos) oldest &= lp == 0 || lp >= J.listpos; }
+                        if (oldest) save_checkpoint(J);
+                        last_save = now;
+                    }
+                }
+                for (auto &x : th) x.join();
+                // drain the checker queue, then stop it
+                for (;;) { { std::lock_guard<std::mutex> lk(J.chk_mutex); if (J.checker.empty()) break; } if (J.quit.load()) break; std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
+                J.all_done = true; J.chk_cv.notify_all();
+                for (auto &x : chk) x.join();
+            } else { J.winkey = trivial; J.found = true; }
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (J.found) {                                                  // win.txt 1_9_7File.pb:5146-5160
+                const std::string head = "KEY[" + std::to_string(J.listpos) + "]: ";
+                const std::string l1 = head + "0x" + hs::fe_to_hex(J.winkey);
+                const std::string l2 = std::string(head.size() - 5, ' ') + "Pub: " + hs::compress_pubkey(J.realpub);
+                say("\n****************************\n%s\n%s\n****************************\n", l1.c_str(), l2.c_str());
+                o.found = true; o.win = l1 + "\r\n" + l2 + "\r\n";
+            } else say("\nReached end of space\n");
+            say("Job time %.2fs, %llu tiles, %.3e giant steps\n", secs, (unsigned long long)J.tiles_done.load(), (double)J.steps_done.load());
+            say("Checker: %llu hits resolved in %.3fs of CPU time (%.2f%% of one core)\n", (unsigned long long)J.hits_checked.load(), J.checker_ns.load() * 1e-9,
+                secs > 0 ? 100.0 * J.checker_ns.load() * 1e-9 / secs : 0.0);
+            { std::lock_guard<std::mutex> lk(out_mutex); o.done = true; emit(); }
+        }
+    };
+    {
+        std::vector<std::thread> lt;
+        for (size_t l = 1; l < lanes; l++) lt.emplace_back(run_lane, l);
+        run_lane(0);
+        for (auto &t : lt) t.join();
+        std::lock_guard<std::mutex> lk(out_mutex);
+        emit();
+    }
     if (S.joblog) fclose(S.joblog);
     printf("Found %d of %zu\n", finditems, pubs.size());
-    return 0;
+    fflush(stdout);
+    if (getenv("BSGS_HOST_CLEAN_EXIT")) { for (bsgs_dev *d : devs) bsgs_dev_close(d); return 0; }
+    // the search is over and every file is on disk: leave without the runtime's teardown (freeing a few hundred GiB of device memory buffer by buffer and unloading
+    // the code objects costs 0.15-0.3 s of a 64-bit solve that takes one; the driver reclaims everything with the process)
+    _exit(0);
 }

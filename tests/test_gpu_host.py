@@ -137,7 +137,9 @@ def test_config4_style_many_keys_64bit_range(tmp_path):
     lines = win_lines(tmp_path)
     got = [int(l.split("0x")[1], 16) for l in lines if l.startswith("KEY[")]
     assert got == keys
-    assert out.count("memory") == 1                                      # one device, opened and loaded once
+    # devices are opened and loaded once, not once per key; round 5: jobs this short (1025 tiles) run two at a time, each on an engine of its own on the one GPU
+    assert out.count("memory") == 2 and "two public keys searched side by side" in out
+    assert [l for l in out.splitlines() if l.startswith("Findpubkey")] == ["Findpubkey  : " + ("03" if ecpy.mul(k)[1] & 1 else "02") + "%064x" % ecpy.mul(k)[0] for k in keys]   # console in list order
 
 
 def test_extended_table_mode_small_and_puzzle64(tmp_path):

@@ -193,3 +193,44 @@ def test_bench_two_ranks_three_startup_strategies(tmp_path):
             res[st] = (d["per_rank"][0]["table_checksums"], json.load(f)["hits"])
     assert res["broadcast"] == res["local"] == res["allgather"]
     assert len(res["local"][1]) >= 1
+
+
+def test_lanes_two_jobs_side_by_side_keep_list_order_and_recovery(tmp_path):
+    """BASELINE config 4's shape in small: 12 public keys over a fixed range whose jobs are a launch or two long.  `-lanes 2` (the automatic choice for such jobs) searches two
+    keys side by side, each on an engine of its own on the one GPU; win.txt, the console and "Found n of m" must be what `-lanes 1` gives, in list order -- including a key
+    outside the range ("Reached end of space") in the middle of the list; and -wl resumes at a list position with both lanes."""
+    import hashlib
+    from pybsgs import ecpy
+    t, b, p, wexp, htsz = 64, 8, 16, 16, 13
+    lo, hi = 1 << 40, (1 << 41) - 1
+    keys, st = [], 0xBEEF
+    for i in range(12):
+        st, r = ecpy.splitmix64(st)
+        keys.append(lo + r % (hi - lo))
+    keys[5] = hi + 12345678901                                    # not in the range: its job ends with "Reached end of space"
+    infile = tmp_path / "pubs.txt"
+    infile.write_text("\n".join("%064x%064x" % ecpy.mul(k) for k in keys) + "\n")
+    geo = ["-t", str(t), "-b", str(b), "-p", str(p), "-w", str(wexp), "-htsz", str(htsz), "-infile", str(infile), "-pk", "%x" % lo, "-pke", "%x" % hi]
+    res = {}
+    for lanes in ("1", "2"):
+        d = tmp_path / ("l" + lanes)
+        d.mkdir()
+        r = _host(geo + ["-lanes", lanes], d)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        win = (d / "win.txt").read_bytes().decode().split("\r\n")
+        res[lanes] = ([l for l in win if l.startswith("KEY[")], [l for l in r.stdout.splitlines() if l.startswith(("Findpubkey", "KEY[", "Reached end"))], r.stdout)
+        assert "Found 11 of 12" in r.stdout
+    assert res["1"][0] == res["2"][0] == ["KEY[%d]: 0x%064x" % (i + 1, k) for i, k in enumerate(keys) if i != 5]
+    assert res["1"][1] == res["2"][1]                              # same lines, same order on the console
+    assert res["2"][2].count("memory") == 2 and res["1"][2].count("memory") == 1
+    # recovery at list position 7 with two lanes: positions 7..12 are searched (position 7 from the saved counter), nothing before
+    gstep = 4 * t * b * p * (1 << wexp)
+    cnt = 1 + max(0, (keys[6] - lo) // gstep - 1) * gstep
+    fp = hashlib.sha1(("%d%d%d%d%s%s%d" % (t, b, p, 1 << wexp, "%x" % lo, "%x" % hi, htsz)).encode()).hexdigest()
+    d = tmp_path / "rec"
+    d.mkdir()
+    (d / "currentwork.txt").write_bytes(("7\r\n%064x%064x\r\n%064x\r\n%s\r\n" % (ecpy.mul(keys[6]) + (cnt, fp))).encode())
+    r = _host(geo + ["-lanes", "2", "-wl", str(d / "currentwork.txt")], d)
+    assert r.returncode == 0 and "Recovery: listpos 7" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+    win = [l for l in (d / "win.txt").read_bytes().decode().split("\r\n") if l.startswith("KEY[")]
+    assert win == ["KEY[%d]: 0x%064x" % (i + 1, k) for i, k in enumerate(keys) if i >= 6]

@@ -2,7 +2,7 @@
 """BASELINE config 3 for real: one public key in an 80-bit range, -t 256 -b 256 -p 256 -w 34 -htsz 31 (2^34 baby points, 128 GiB of
 bucket lines built in GPU memory), the key `frac` of the way into the range.  Prints one JSON line (measured time-to-solve).
 
-  tools/config3_run.py [frac=0.25] [workdir=/tmp/cfg3]
+  tools/config3_run.py [frac=0.25] [workdir=/tmp/cfg3] [table flags, default "-w 34 -htsz 31"; round 5: "-w 35 -buckets 1610612736", or "-w auto" = Tune's choice for the range]
 """
 import json
 import os
@@ -18,12 +18,14 @@ from pybsgs import ecpy  # noqa: E402
 def main():
     frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
     wd = sys.argv[2] if len(sys.argv) > 2 else "/tmp/cfg3"
+    table = (sys.argv[3] if len(sys.argv) > 3 else "-w 34 -htsz 31").split()
+    wlog = 35 if ("35" in table or "auto" in table) else 34
     os.makedirs(wd, exist_ok=True)
     start, end = 1 << 79, (1 << 80) - 1
     key = start + int(frac * (end - start)) + 0x9E3779B97F4A7C15
     exe = os.path.join(ROOT, "bsgs-cuda_amd", "build", "bsgs_mi355x")
     t0 = time.time()
-    res = subprocess.run([exe, "-dir", wd, "-t", "256", "-b", "256", "-p", "256", "-w", "34", "-htsz", "31", "-pb", "%064x%064x" % ecpy.mul(key),
+    res = subprocess.run([exe, "-dir", wd, "-t", "256", "-b", "256", "-p", "256"] + table + ["-pb", "%064x%064x" % ecpy.mul(key),
                           "-pk", "%x" % start, "-pke", "%x" % end], capture_output=True, text=True)
     dt = time.time() - t0
     found = None
@@ -34,12 +36,13 @@ def main():
     except OSError:
         pass
     job = [l for l in res.stdout.splitlines() if l.startswith("Job time")]
-    rec = {"config": "single pubkey, 80-bit range 2^79..2^80-1, -t 256 -b 256 -p 256 -w 34 -htsz 31, 1 GPU", "key_fraction_into_range": frac,
+    rec = {"config": "single pubkey, 80-bit range 2^79..2^80-1, -t 256 -b 256 -p 256 %s, 1 GPU" % " ".join(table), "key_fraction_into_range": frac,
            "key": "%x" % key, "found": found == key, "process_wall_s_incl_table_build": dt, "returncode": res.returncode}
     if job:
         f = job[0].split()
         rec.update({"job_time_s": float(f[2].rstrip("s,")), "tiles": int(f[3]), "giant_steps": int(f[3]) * 2**25,
-                    "giant_steps_per_s": int(f[3]) * 2**25 / float(f[2].rstrip("s,")), "keys_covered": int(f[3]) * 4 * 2**24 * 2**34})
+                    "giant_steps_per_s": int(f[3]) * 2**25 / float(f[2].rstrip("s,")), "keys_covered": int(f[3]) * 4 * 2**24 * 2**wlog})
+    rec["startup"] = [l for l in res.stdout.splitlines() if l.startswith("[startup]") or l.startswith("Tune for this range") or l.startswith("-w auto")]
     chk = [l for l in res.stdout.splitlines() if l.startswith("Checker:")]
     if chk:
         rec["checker"] = chk[0]
