@@ -301,11 +301,11 @@ static int set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p)
 }
 
 static bool lines_layout(const bsgs_dev *d) { return d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128; }
-// threads per workgroup of the tile kernel: four waves with 64-byte lines (10 KiB of LDS per wave: four blocks fill a CU), two with 128-byte lines (14 KiB per wave: five
-// blocks = ten waves per CU; four-wave blocks would stop at eight).  BSGS_LINES128_BLOCK=256 is the A-B switch.
+// threads per workgroup of the tile kernel: four waves (10 KiB of LDS per wave with 64-byte lines: four blocks fill a CU; the 128-byte-line kernel, compiled for three waves
+// per SIMD, runs three such blocks per CU).  BSGS_LINES128_BLOCK=128 gives the 128-byte-line kernel two-wave blocks (A-B: six blocks per CU instead of three).
 static unsigned tile_block(const bsgs_dev *d)
 {
-    static const unsigned b128 = getenv("BSGS_LINES128_BLOCK") ? (unsigned)atoi(getenv("BSGS_LINES128_BLOCK")) : 128u;
+    static const unsigned b128 = getenv("BSGS_LINES128_BLOCK") ? (unsigned)atoi(getenv("BSGS_LINES128_BLOCK")) : 256u;
     return d->layout == BSGS_TABLE_LINES128 && (b128 == 128u || b128 == 256u) ? b128 : d->block_size;
 }
 // giants per stored running product of the tile kernel a launch with batch length `pi` takes: 4 / 2 = the chained kernel (giant_pair2_kernel,
@@ -707,8 +707,9 @@ static const bsgs_dev::Batching *pick_batching(bsgs_dev *d, uint32_t ntiles)
     const uint64_t bytes = d->maxnonce * 64;
     bsgs_dev::Batching nb;
     nb.pi = pi; nb.Ti = (uint32_t)(d->maxnonce / pi);
-    if (!d->narrow.empty()) {                                    // re-use the resident copy's memory: launches in flight may still read it
-        if (hipStreamSynchronize(d->stream) != hipSuccess) return nullptr;
+    if (!d->narrow.empty()) {
+        // re-use the resident copy's memory.  Launches in flight may still read it -- they were queued on this very stream, and so is the re-batching pass below:
+        // stream order makes it wait for them, the host does not have to (a synchronisation here turned an asynchronous bsgs_enqueue into a blocking call: ADVICE r04)
         nb.g2 = d->narrow[0].g2;
         d->narrow.clear();
     } else {
@@ -756,7 +757,7 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     // chained kernel, per wave: two probe slots (QUAD: one probe slot + the two 2 KiB temporaries) + the 2 KiB S stash: 4 blocks fill the 160 KiB of a CU exactly
     const bool l128 = d->layout == BSGS_TABLE_LINES128;
     const size_t slot = l128 ? 8192 : 4096;
-    const size_t lds = group > 1 ? (size_t)(bs / 64) * ((group == 4 ? slot + 4096 : 2 * slot) + 2048) : 0;
+    const size_t lds = group > 1 ? (size_t)(bs / 64) * ((group == 4 ? (l128 ? slot : slot + 4096) : 2 * slot) + 2048) : 0;       // giant_pair2_kernel: REGION + 2 KiB of stash per wave
     const bool dbg = d->debug_flags != 0 || d->phase_probe;
     if (d->layout == BSGS_TABLE_LINES64) HIPCHK(bsgs_launch_tile_lines64(A, grid, block, lds, st, group, dbg, &d->last_kernel));
     else if (l128)                       HIPCHK(bsgs_launch_tile_lines128(A, grid, block, lds, st, group, dbg, &d->last_kernel));

@@ -1028,7 +1028,8 @@ int main(int argc, char **argv)
     if (short_job) {
         // about six batches per GPU and job (ten with two lanes: the other lane's launch hides this one's boundaries), not below 16 (8) tiles: the narrow batchings keep
         // small launches at 35-38 G, and with the key anywhere in the range 0.55-0.6 of the tiles are searched on average instead of all of them
-        S.batch_hint = (uint32_t)std::min(tpl_est, std::max(lanes > 1 ? 8.0 : 16.0, std::ceil(job_tiles / ((lanes > 1 ? 10.0 : 6.0) * (double)gpus.size()))));
+        const double per_job = getenv("BSGS_SHORT_JOB_BATCHES") ? std::max(1.0, atof(getenv("BSGS_SHORT_JOB_BATCHES"))) : (lanes > 1 ? 10.0 : 6.0);      // (the variable: A-B runs)
+        S.batch_hint = (uint32_t)std::min(tpl_est, std::max(lanes > 1 ? 8.0 : 16.0, std::ceil(job_tiles / (per_job * (double)gpus.size()))));
         printf("Short jobs (%.0f tiles each): dealt in batches of %u tiles%s\n", job_tiles, S.batch_hint, lanes > 1 ? ", two public keys searched side by side (an engine each per GPU)" : "");
     }
     if (lanes > 1) { const std::vector<int> base = gpus; for (size_t l = 1; l < lanes; l++) gpus.insert(gpus.end(), base.begin(), base.end()); }
@@ -1042,11 +1043,10 @@ int main(int argc, char **argv)
     }
     stage("upload, bucket lines, chain scratch, replicas");
     if (!c.joblog.empty()) { S.joblog = fopen(c.joblog.c_str(), "w"); if (!S.joblog) die("Can`t create " + c.joblog); }
-    flush_writers();
+    // freshly generated files keep being written BEHIND the search (their writers are joined before the process leaves; a file appears under its name only once it is
+    // complete: write_file): the 13 GB of HT files of a -w 30 run cost the first jobs nothing.  Only the resolver's table must be there before the first hit.
     if (mini_builder.joinable()) mini_builder.join();
-    stage("files on disk / resolver table (behind the start-up)");
-    std::vector<uint8_t>().swap(htgpu);                               // host staging copies are no longer needed (1_9_7File.pb:4818-4843)
-    std::vector<uint8_t>().swap(g2);
+    stage("resolver table (behind the start-up)");
 
     // ---- the jobs: one public key after the other (1_9_7File.pb:4995-5168) -- or, when a job is only a launch or two long (BASELINE config 4: 1000 keys over a 64-bit
     // range), `lanes` of them side by side, each on an engine of its own per GPU: while one job waits for its checker, dispenses, or parses the next key, the other's
@@ -1205,6 +1205,9 @@ int main(int argc, char **argv)
         emit();
     }
     if (S.joblog) fclose(S.joblog);
+    flush_writers();                                                  // the files that were still being written behind the search
+    std::vector<uint8_t>().swap(htgpu);                               // host staging copies (1_9_7File.pb:4818-4843)
+    std::vector<uint8_t>().swap(g2);
     printf("Found %d of %zu\n", finditems, pubs.size());
     fflush(stdout);
     if (getenv("BSGS_HOST_CLEAN_EXIT")) { for (bsgs_dev *d : devs) bsgs_dev_close(d); return 0; }

@@ -44,3 +44,19 @@ def test_corrected_traffic_divides_every_stream_by_its_own_calibration_ratio():
     # no counters, no figure
     assert bench.corrected_traffic({"calibration_ratios": {}}, steps) is None
     json.dumps(ct)
+
+
+def test_box_independent_figures():
+    """value_per_GHz and nJ_per_giant_step: the same kernel on a faster-clocked box gives a higher rate and the same two figures; a kernel that
+    needs more cycles or more energy per step moves them; ranks add up; missing samples give None, never a made-up number"""
+    bench = _bench()
+    a = bench.box_independent([{"giant_steps_per_s": 41.0e9, "sclk_MHz": 1740.0, "socket_W": 1370.0, "idle_W": 245.0}])
+    b = bench.box_independent([{"giant_steps_per_s": 38.76e9, "sclk_MHz": 1645.0, "socket_W": 1308.5, "idle_W": 245.0}])      # the slow box of round 4: -5.5 % rate
+    assert abs(a["value_per_GHz"] / b["value_per_GHz"] - 1.0) < 0.002 and abs(a["nJ_per_giant_step"] / b["nJ_per_giant_step"] - 1.0) < 0.002
+    assert abs(a["nJ_per_giant_step"] - (1370.0 - 245.0) / 41.0) < 1e-9
+    worse = bench.box_independent([{"giant_steps_per_s": 39.0e9, "sclk_MHz": 1740.0, "socket_W": 1370.0, "idle_W": 245.0}])           # 5 % more cycles per step at the same clock
+    assert worse["value_per_GHz"] < 0.96 * a["value_per_GHz"] and worse["nJ_per_giant_step"] > 1.04 * a["nJ_per_giant_step"]
+    two = bench.box_independent([{"giant_steps_per_s": 41.0e9, "sclk_MHz": 1740.0, "socket_W": 1370.0, "idle_W": None}] * 2)
+    assert abs(two["value_per_GHz"] - 2 * a["value_per_GHz"]) < 1.0 and abs(two["nJ_per_giant_step"] - a["nJ_per_giant_step"]) < 1e-9      # idle defaults to 245 W
+    none = bench.box_independent([{"giant_steps_per_s": 41.0e9, "sclk_MHz": None, "socket_W": None, "idle_W": None}])
+    assert none["value_per_GHz"] is None and none["nJ_per_giant_step"] is None

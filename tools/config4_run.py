@@ -41,7 +41,8 @@ def main():
     print(json.dumps({"config": "-infile %d pubkeys, range 8000000000000000..ffffffffffffffff, -t 256 -b 256 -p 256 -w 30 -htsz 28, 1 GPU" % n,
                       "keys_correct": n - len(missing), "keys": n, "missing": [(i, "%x" % keys[i - 1]) for i in missing[:20]], "wall_s_total_incl_table_build_and_file_save": dt,
                       "search_s_sum": sum(job), "search_s_mean_per_key": sum(job) / max(len(job), 1), "search_s_max": max(job) if job else None,
-                      "tiles_total": sum(tiles), "returncode": res.returncode}))
+                      "tiles_total": sum(tiles), "returncode": res.returncode,
+                      "startup": [l for l in res.stdout.splitlines() if l.startswith("[startup]") or l.startswith("Short jobs")]}))
 
 
 if __name__ == "__main__":
