@@ -202,7 +202,23 @@ static Config parse_args(int argc, char **argv)
 }
 
 // ---- files ---------------------------------------------------------------------------------------------------------------
-static bool read_file(const std::string &path, std::vector<uint8_t> &out, uint64_t expect)
+// the table images on the host (up to 36 GB): plain allocations that are NOT zero-filled first -- a std::vector's resize writes every byte once before the file read or the
+// download from the GPU writes it again, a second and a half for the 12 GiB of a -w 30 run
+struct HostBuf {
+    uint8_t *p = nullptr;
+    uint64_t n = 0;
+    HostBuf() {}
+    HostBuf(const HostBuf &) = delete;
+    HostBuf &operator=(const HostBuf &) = delete;
+    ~HostBuf() { free(p); }
+    void resize(uint64_t bytes) { free(p); p = bytes ? (uint8_t *)malloc(bytes) : nullptr; n = p ? bytes : 0; if (bytes && !p) { fprintf(stderr, "out of host memory (%llu bytes)\n", (unsigned long long)bytes); exit(1); } }
+    void release() { free(p); p = nullptr; n = 0; }
+    uint8_t *data() { return p; }
+    const uint8_t *data() const { return p; }
+    uint64_t size() const { return n; }
+    const uint8_t &operator[](uint64_t i) const { return p[i]; }
+};
+static bool read_file(const std::string &path, HostBuf &out, uint64_t expect)
 {
     std::ifstream f(path, std::ios::binary | std::ios::ate);
     if (!f) return false;
@@ -242,7 +258,7 @@ struct MiniBsgs {
 
 // what every job of a run reads and nobody writes once the start-up is over: the resolver's tables
 struct Tables {
-    std::vector<uint8_t> htcpu;
+    HostBuf htcpu;
     MiniBsgs mini;                                // extended tables: the resolver's own small BSGS instead of htCPU
 };
 struct Tile { Scalar key; uint64_t index; };          // counter and dispenser index of a tile: centre = walk_p0 + index * PUBADDBIG
@@ -321,7 +337,7 @@ static size_t get_jobs(Shared &S, size_t n, std::vector<Tile> &out, int slot = -
 }
 
 // ---- resolver: checkerThread 1_9_7File.pb:3933-4296 ---------------------------------------------------------------
-static int htcpu_lookup(const std::vector<uint8_t> &img, uint64_t ht_items, uint64_t key64, uint32_t *pos, int max)
+static int htcpu_lookup(const HostBuf &img, uint64_t ht_items, uint64_t key64, uint32_t *pos, int max)
 {
     const uint32_t b = (uint32_t)key64 & (uint32_t)(ht_items - 1), h = (uint32_t)(key64 >> 32);
     uint32_t lo, hi;
@@ -530,7 +546,7 @@ static void per_gpu(const std::vector<int> &gpus, const std::function<void(size_
 //   local      every engine takes / builds its own, concurrently: the reference's shape for file tables, and NO link traffic at all for extended tables (default there);
 //   allgather  extended tables: every engine builds the lines of 1/N of the buckets, then all-gather.
 // Every engine allocates its chain scratch (placed by grade: the reference's cuMemAlloc_v2 before its loop, 1_9_7File.pb:2251) right after its table.
-static void load_engines(const Shared &S, const std::vector<int> &gpus, const std::vector<bsgs_dev *> &devs, const std::vector<uint8_t> &htgpu, const std::vector<uint8_t> &g2)
+static void load_engines(const Shared &S, const std::vector<int> &gpus, const std::vector<bsgs_dev *> &devs, const HostBuf &htgpu, const HostBuf &g2)
 {
     const Config &c = S.cfg;
     const size_t n = devs.size();
@@ -947,7 +963,7 @@ int main(int argc, char **argv)
     const std::string stem = c.dir + "/" + gxhex + "_" + std::to_string(c.w) + "_" + std::to_string(ht_items);
     const std::string f_gpu = stem + "_htGPUv0.BIN", f_cpu = stem + "_htCPUv0.BIN";
     const std::string f_g2 = c.dir + "/" + std::to_string(c.t) + "_" + std::to_string(c.b) + "_" + std::to_string(c.p) + "_" + std::to_string(c.w) + "_g2.BIN";
-    std::vector<uint8_t> htgpu, g2;
+    HostBuf htgpu, g2;
     // files that were just generated are written by background threads while the start-up goes on (upload, bucket lines, scratch): the buffers they read
     // stay alive until `flush_writers` -- before the staging copies are released, and before any return
     std::vector<std::thread> writers;
@@ -1026,9 +1042,9 @@ int main(int argc, char **argv)
     else if (short_job && todo >= 4 && !c.ext && c.joblog.empty()) lanes = 2;
     lanes = std::max<size_t>(1, std::min(lanes, todo));
     if (short_job) {
-        // about six batches per GPU and job (ten with two lanes: the other lane's launch hides this one's boundaries), not below 16 (8) tiles: the narrow batchings keep
+        // about six batches per GPU and job (fourteen with two lanes: the other lane's launch hides this one's boundaries), not below 16 (8) tiles: the narrow batchings keep
         // small launches at 35-38 G, and with the key anywhere in the range 0.55-0.6 of the tiles are searched on average instead of all of them
-        const double per_job = getenv("BSGS_SHORT_JOB_BATCHES") ? std::max(1.0, atof(getenv("BSGS_SHORT_JOB_BATCHES"))) : (lanes > 1 ? 10.0 : 6.0);      // (the variable: A-B runs)
+        const double per_job = getenv("BSGS_SHORT_JOB_BATCHES") ? std::max(1.0, atof(getenv("BSGS_SHORT_JOB_BATCHES"))) : (lanes > 1 ? 14.0 : 6.0);      // (the variable: A-B runs; 1000 keys of config 4: 10 -> 64-66 s, 14 -> 61.8 s, profiles/r07g_*)
         S.batch_hint = (uint32_t)std::min(tpl_est, std::max(lanes > 1 ? 8.0 : 16.0, std::ceil(job_tiles / (per_job * (double)gpus.size()))));
         printf("Short jobs (%.0f tiles each): dealt in batches of %u tiles%s\n", job_tiles, S.batch_hint, lanes > 1 ? ", two public keys searched side by side (an engine each per GPU)" : "");
     }
@@ -1206,8 +1222,8 @@ int main(int argc, char **argv)
     }
     if (S.joblog) fclose(S.joblog);
     flush_writers();                                                  // the files that were still being written behind the search
-    std::vector<uint8_t>().swap(htgpu);                               // host staging copies (1_9_7File.pb:4818-4843)
-    std::vector<uint8_t>().swap(g2);
+    htgpu.release();                                                  // host staging copies (1_9_7File.pb:4818-4843)
+    g2.release();
     printf("Found %d of %zu\n", finditems, pubs.size());
     fflush(stdout);
     if (getenv("BSGS_HOST_CLEAN_EXIT")) { for (bsgs_dev *d : devs) bsgs_dev_close(d); return 0; }

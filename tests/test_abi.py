@@ -164,3 +164,23 @@ def test_grader_stop_and_keep_rule_without_a_device(libpath):
     # fewer candidates than needed: everything there is, marked
     drawn, kept, sep = rule([41.0, 38.0], 4)
     assert drawn == 2 and kept[2:] == [0xFFFFFFFF] * 2
+
+
+def test_production_tile_kernels_do_not_spill(tmp_path):
+    """The register budget of the hot kernels, checked where they are built (cross-compilation: no GPU).  giant_pair2_kernel<2, false, true> -- what bench.py times -- at
+    four waves per SIMD: at most 128 VGPRs, NO spilled VGPR, NO scratch (round 4 shipped 34 spilled VGPRs and 144 bytes of scratch per lane); and the 128-byte-line kernel
+    <3, false, true> at three waves per SIMD: at most 168 VGPRs, no spilled VGPR (round 4: 39 spilled, ten scratch loads inside the probe loop)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    for tu, kernel, max_vgpr in (("tile_lines64.hip", "_Z18giant_pair2_kernelILi2ELb0ELb1EEv8TileArgs", 128), ("tile_lines128.hip", "_Z18giant_pair2_kernelILi3ELb0ELb1EEv8TileArgs", 168)):
+        asm = tmp_path / (tu + ".s")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only", "-o", str(asm),
+                               os.path.join(ROOT, "bsgs-cuda_amd", "csrc", tu)], stderr=subprocess.DEVNULL)
+        text = asm.read_text()
+        meta = text[text.index(".name:           " + kernel):][:900]
+        get = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", meta).group(1))      # noqa: E731
+        assert get("vgpr_spill_count") == 0, (tu, meta)
+        assert get("vgpr_count") <= max_vgpr, (tu, meta)
+        if tu == "tile_lines64.hip":
+            assert get("private_segment_fixed_size") == 0, (tu, meta)

@@ -7,7 +7,8 @@ production kernel), one per library:
     build/exp_nochain   (-DBSGS_NOCHAIN_CEILING)     no chain stores, no chain fetches           -> chain  = shipped - this
     build/exp_g2cached  (-DBSGS_G2_CACHED_CEILING)   every giant read served from one cached KiB -> giants = shipped - this
 and probe = the rest.  The two experiment libraries return wrong hit lists by construction (bsgs_build_info says so); only their counters are used.
-Build them first:  make -C bsgs-cuda_amd -j8 BUILD=build/exp_nochain EXTRA="-DBSGS_EXPERIMENT -DBSGS_NOCHAIN_CEILING" build/exp_nochain/libbsgs_hip.so  (likewise g2cached)."""
+Build them first (round 5: the experiments are written into a COPY of csrc/, the shipped kernel has none):
+    tools/experiments/build_experiment.sh nochain "-DBSGS_EXPERIMENT -DBSGS_NOCHAIN_CEILING" ; tools/experiments/build_experiment.sh g2cached "-DBSGS_EXPERIMENT -DBSGS_G2_CACHED_CEILING"."""
 import csv
 import glob
 import json
