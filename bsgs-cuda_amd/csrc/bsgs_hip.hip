@@ -1274,6 +1274,26 @@ extern "C" int bsgs_broadcast_tables_ex(bsgs_dev *const *devs, int n, uint32_t t
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return BSGS_OK;
 }
+// Two engines on one GPU probing ONE table (the host's lanes): the twin borrows the owner's table buffers and copies the giants.
+extern "C" int bsgs_share_tables(bsgs_dev *s, bsgs_dev *d)
+{
+    if (!s || !d || s == d) return fail(BSGS_ERR_ARG, "two different engines");
+    if (s->id != d->id) return fail(BSGS_ERR_ARG, "engines on GPU %d and GPU %d: a table is shared on ONE GPU only (replicas elsewhere: bsgs_broadcast_tables)", s->id, d->id);
+    if (!s->g2 || !s->layout) return fail(BSGS_ERR_STATE, "the owner must hold the giants and the table");
+    if (d->queued) return fail(BSGS_ERR_STATE, "tiles are queued on the twin");
+    HIPCHK(hipSetDevice(d->id));
+    int r = set_geometry(d, s->t, s->b, s->p);
+    if (r) return r;
+    if (d->Ti != s->Ti || d->pi != s->pi) return fail(BSGS_ERR_STATE, "the twin chose another batching");
+    HIPCHK(hipStreamSynchronize(s->stream));                          // whatever built the owner's buffers is done
+    HIPCHK(hipMemcpyAsync(d->g2, s->g2, s->maxnonce * 64, hipMemcpyDeviceToDevice, d->stream));
+    free_table(d);
+    d->csr = s->csr; d->csr_owned = false;
+    d->lines = s->lines; d->ovf = s->ovf; d->ovf_n = s->ovf_n; d->lines_owned = false;
+    d->ht_items = s->ht_items; d->w = s->w; d->overflow = s->overflow; d->lines_bytes = s->lines_bytes; d->layout = s->layout; d->bucket_mul = s->bucket_mul;
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return BSGS_OK;
+}
 extern "C" int bsgs_broadcast_tables(bsgs_dev *const *devs, int n)
 {
     if (n == 1 && devs && devs[0]) return (devs[0]->g2 && devs[0]->layout) ? BSGS_OK : fail(BSGS_ERR_STATE, "devs[0] must hold the giants and the table");

@@ -1053,8 +1053,18 @@ int main(int argc, char **argv)
     {
         for (size_t gi = 0; gi < gpus.size(); gi++) devs[gi] = open_dev(gpus[gi]);
         if (S.batch_hint) for (bsgs_dev *d : devs) CK(bsgs_set_tiles_per_launch(d, S.batch_hint));     // scratch (and its placement) for the batches this run will launch, not for 192 tiles
-        load_engines(S, gpus, devs, htgpu, g2);
-        if (devs.size() > 1 && c.verify_replicas) verify_replicas(gpus, devs);
+        // the engines of lane 0 are loaded (and, several GPUs, compared); the engines of the other lanes are TWINS of theirs on the same GPU: they probe the same table in
+        // place (bsgs_share_tables) -- no second 21 GiB to place, clear and copy at -w 30 -- with giants and chain scratch of their own
+        const size_t primaries = gpus.size() / lanes;
+        const std::vector<int> gpus0(gpus.begin(), gpus.begin() + (long)primaries);
+        const std::vector<bsgs_dev *> devs0(devs.begin(), devs.begin() + (long)primaries);
+        load_engines(S, gpus0, devs0, htgpu, g2);
+        if (devs0.size() > 1 && c.verify_replicas) verify_replicas(gpus0, devs0);
+        if (lanes > 1) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (size_t gi = primaries; gi < devs.size(); gi++) { CK(bsgs_share_tables(devs[gi % primaries], devs[gi])); CK(bsgs_prepare(devs[gi])); print_placement(gpus[gi], gi, devs[gi]); }
+            printf("[startup] %-44s %.3fs\n", "twin engines of the other lanes (shared tables)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
         if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }
     }
     stage("upload, bucket lines, chain scratch, replicas");
@@ -1226,7 +1236,7 @@ int main(int argc, char **argv)
     g2.release();
     printf("Found %d of %zu\n", finditems, pubs.size());
     fflush(stdout);
-    if (getenv("BSGS_HOST_CLEAN_EXIT")) { for (bsgs_dev *d : devs) bsgs_dev_close(d); return 0; }
+    if (getenv("BSGS_HOST_CLEAN_EXIT")) { for (size_t gi = devs.size(); gi-- > 0;) bsgs_dev_close(devs[gi]); return 0; }      // twins (borrowed tables) before their owners
     // the search is over and every file is on disk: leave without the runtime's teardown (freeing a few hundred GiB of device memory buffer by buffer and unloading
     // the code objects costs 0.15-0.3 s of a 64-bit solve that takes one; the driver reclaims everything with the process)
     _exit(0);

@@ -26,7 +26,7 @@ NATIVE_SYMBOLS = [
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_quirk_count", "bsgs_broadcast_tables",
     "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_chain_grades", "bsgs_debug_grade_rule", "bsgs_debug_xcd_profile",
     "bsgs_table_checksum", "bsgs_debug_corrupt_table", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
-    "bsgs_table_census", "bsgs_table_lookup", "bsgs_broadcast_tables_ex", "bsgs_startup_ext_tables", "bsgs_build_baby_table_ext_slice", "bsgs_build_overflow_set", "bsgs_debug_fabric_selftest",
+    "bsgs_table_census", "bsgs_table_lookup", "bsgs_broadcast_tables_ex", "bsgs_startup_ext_tables", "bsgs_build_baby_table_ext_slice", "bsgs_build_overflow_set", "bsgs_debug_fabric_selftest", "bsgs_share_tables",
 ]
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
@@ -141,6 +141,7 @@ def lib():
             "bsgs_set_flags": [vp, C.c_uint32],
             "bsgs_quirk_count": [vp, C.POINTER(C.c_uint32)],
             "bsgs_broadcast_tables": [C.POINTER(vp), C.c_int],
+            "bsgs_share_tables": [vp, vp],
             "bsgs_tiles_per_launch": [vp, C.POINTER(C.c_uint32)],
             "bsgs_engine_geometry": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
             "bsgs_debug_last_batching": [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
@@ -180,6 +181,11 @@ def broadcast_tables(devices):
     """replicas of devices[0]'s giants and table on the other Device objects (device-to-device copies; the same GPU may appear twice)"""
     arr = (C.c_void_p * len(devices))(*[d.h for d in devices])
     _chk(lib().bsgs_broadcast_tables(arr, len(devices)))
+
+
+def share_tables(owner, twin):
+    """two engines on one GPU: `twin` probes `owner`'s table in place (borrowed) and gets its own copy of the giants"""
+    _chk(lib().bsgs_share_tables(owner.h, twin.h))
 
 
 TRANSPORT_AUTO, TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1, 2

@@ -71,6 +71,41 @@ def test_three_startup_strategies_give_byte_identical_tables_on_two_engines(w, h
     assert len({tuple(v) for v in seen.values()}) == 1
 
 
+@pytest.mark.parametrize("layout", ["image", 4, 5])
+def test_twin_engine_shares_the_owners_table_in_place(layout):
+    """bsgs_share_tables (the host's lanes: two public keys searched side by side on one GPU): the twin probes the owner's buffers -- same checksums, same hits, nothing of
+    the table owned by it --, keeps working next to the owner, and its going leaves the owner's table untouched.  Engines on different GPUs are refused (same GPU here:
+    the refusal of an engine as its own twin is what a one-GPU lease can show)."""
+    import pybsgs
+    from pybsgs import ecpy
+    w, t, b, p = 1 << 18, 64, 8, 16
+    ms, centres = _centres(w, t * b * p)
+    A = ecpy.addpubg(w)
+    own, twin = pybsgs.Device(0), pybsgs.Device(0)
+    own.generate_g2(A[0], A[1], t, b, p)
+    if layout == "image":
+        own.build_baby_tables(w, 14, install_layout=pybsgs.TABLE_LINES64)
+    else:
+        own.build_baby_table_ext(w, 13, layout)
+    want, nw, _ = own.run(centres, 65536)
+    free_before = own.meminfo()[0]
+    pybsgs.share_tables(own, twin)
+    assert own.meminfo()[0] > free_before - (64 << 20)             # the giants (512 KiB here) and nothing like a table
+    assert twin.table_checksum() == own.table_checksum() and twin.table_info() == own.table_info()
+    assert not twin.table_owned() and own.table_owned()
+    for d in (twin, own, twin):
+        got, ng, _ = d.run(centres, 65536)
+        assert (ng, got) == (nw, want)
+    with pytest.raises(pybsgs.BsgsError, match="two different engines"):
+        pybsgs.share_tables(own, own)
+    sums = own.table_checksum()
+    twin.close()
+    assert own.table_checksum() == sums
+    got, ng, _ = own.run(centres, 65536)
+    assert (ng, got) == (nw, want)
+    own.close()
+
+
 def test_allgather_falls_back_when_the_buckets_do_not_divide():
     import pybsgs
     devs = [pybsgs.Device(0) for _ in range(3)]

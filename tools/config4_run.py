@@ -2,7 +2,7 @@
 """BASELINE config 4: -infile with N public keys searched sequentially over the fixed 64-bit range 8000000000000000..
 ffffffffffffffff at -w 30 -htsz 28 on one GPU (k_n = 2^63 + splitmix64(n) >> 1).  Prints one JSON line.
 
-  tools/config4_run.py [N=1000] [workdir=/tmp/cfg4]
+  tools/config4_run.py [N=1000] [workdir=/tmp/cfg4] ["extra host flags", e.g. "-lanes 3"]
 """
 import json
 import os
@@ -18,6 +18,7 @@ from pybsgs import ecpy  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     wd = sys.argv[2] if len(sys.argv) > 2 else "/tmp/cfg4"
+    extra = sys.argv[3].split() if len(sys.argv) > 3 else []
     os.makedirs(wd, exist_ok=True)
     keys, st = [], 0xC0FFEE
     for _ in range(n):
@@ -29,7 +30,7 @@ def main():
     exe = os.path.join(ROOT, "bsgs-cuda_amd", "build", "bsgs_mi355x")
     t0 = time.time()
     res = subprocess.run([exe, "-dir", wd, "-t", "256", "-b", "256", "-p", "256", "-w", "30", "-htsz", "28", "-infile", os.path.join(wd, "pubs.txt"),
-                          "-pk", "8000000000000000", "-pke", "ffffffffffffffff"], capture_output=True, text=True)
+                          "-pk", "8000000000000000", "-pke", "ffffffffffffffff"] + extra, capture_output=True, text=True)
     dt = time.time() - t0
     got = {}
     for l in open(os.path.join(wd, "win.txt"), "rb").read().decode().split("\r\n"):
@@ -38,7 +39,7 @@ def main():
     missing = [i + 1 for i in range(n) if got.get(i + 1) != keys[i]]
     job = [float(l.split()[2][:-2]) for l in res.stdout.splitlines() if l.startswith("Job time")]
     tiles = [int(l.split()[3]) for l in res.stdout.splitlines() if l.startswith("Job time")]
-    print(json.dumps({"config": "-infile %d pubkeys, range 8000000000000000..ffffffffffffffff, -t 256 -b 256 -p 256 -w 30 -htsz 28, 1 GPU" % n,
+    print(json.dumps({"config": "-infile %d pubkeys, range 8000000000000000..ffffffffffffffff, -t 256 -b 256 -p 256 -w 30 -htsz 28%s, 1 GPU" % (n, "".join(" " + e for e in extra)),
                       "keys_correct": n - len(missing), "keys": n, "missing": [(i, "%x" % keys[i - 1]) for i in missing[:20]], "wall_s_total_incl_table_build_and_file_save": dt,
                       "search_s_sum": sum(job), "search_s_mean_per_key": sum(job) / max(len(job), 1), "search_s_max": max(job) if job else None,
                       "tiles_total": sum(tiles), "returncode": res.returncode,
