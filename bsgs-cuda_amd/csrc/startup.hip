@@ -182,8 +182,8 @@ int bsgs_fabric_broadcast(bsgs_fabric *f, void *const *bufs, size_t bytes, int r
 int bsgs_fabric_allgather(bsgs_fabric *f, void *const *bufs, size_t slice_bytes)
 {
     const int n = (int)f->devs.size();
-    if (!slice_bytes || n == 1) return fabric_sync(f);
-    if (f->rccl) {
+    if (!slice_bytes || (n == 1 && !f->rccl)) return fabric_sync(f);
+    if (f->rccl) {                                                // (one rank: the collective is still issued -- in place, nothing moves -- so that a one-GPU lease exercises the call)
         RcclApi &R = rccl_api();
         NCCLCHK(f, R.GroupStart());
         for (int i = 0; i < n; i++) {
