@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 // Point generation: thread tid walks S_tid + j*(T*G), S_tid = (first + tid)*G, j = 0..pi-1, with the tile kernel's batched inverse over its pi
@@ -333,6 +334,14 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
     size_t fr = 0, tot = 0;
     HIPCHK(bsgs_mem_available(&fr, &tot));
     const uint64_t need = KeyGen::scratch_bytes(w) + (64ull << 20);
+    if (need > fr && d->group0_reserve.size() > 8) {                 // the reserve for the chain scratch was sized for a table with a small overflow set: give most of it back
+        trim_reserve(d, 8);
+        for (int k = 0; k < 100; k++) {                               // the driver wipes what it got back before it hands it out again (about 45 GB/s)
+            HIPCHK(bsgs_mem_available(&fr, &tot));
+            if (need <= fr) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+    }
     if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table build needs %.1f GiB of scratch, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
     DevBuf cnt;
     HIPCHK(hipMemsetAsync(lines, 0, nlines * line_bytes, d->stream));

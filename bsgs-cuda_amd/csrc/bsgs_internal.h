@@ -101,7 +101,8 @@ hipError_t bsgs_big_free(void *p);                           // releases what bs
 hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes);       // bucket lines: the candidate in the gather-slow memory class (bsgs_hip.hip)
 // placement.hip
 void free_chain_pieces(bsgs_dev *d);                        // the graded pieces of the chain scratch
-void free_reserve(bsgs_dev *d);                             // the memory group held back for the scratch of a large table
+void free_reserve(bsgs_dev *d);
+void trim_reserve(bsgs_dev *d, size_t keep);                // ... all but `keep` pieces of it                             // the memory group held back for the scratch of a large table
 void release_grader(bsgs_dev *d);
 void park_release(int device);                              // hand every parked piece of this device back to the driver
 uint64_t parked_bytes(int device);                          // bytes this process has parked on the device

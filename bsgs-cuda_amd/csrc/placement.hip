@@ -243,6 +243,11 @@ void free_reserve(bsgs_dev *d)
     for (void *p : d->group0_reserve) (void)bsgs_big_free(p);
     d->group0_reserve.clear();
 }
+// hand back all but `keep` pieces of the reserve (the table builder found the GPU too full for its scratch: a fuller table than the reserve was sized for)
+void trim_reserve(bsgs_dev *d, size_t keep)
+{
+    while (d->group0_reserve.size() > keep) { (void)bsgs_big_free(d->group0_reserve.back()); d->group0_reserve.pop_back(); }
+}
 void free_chain_pieces(bsgs_dev *d)
 {
     for (u32x4 *p : d->chain_pieces) (void)bsgs_big_free(p);

@@ -18,3 +18,16 @@ def small_fx():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "small_w1024_ht8_t2_b2_p4.json")) as f:
         return json.load(f)
+
+
+def free_hbm(want_bytes, wait_s=20.0):
+    """free memory of GPU 0, giving a previous test's process up to `wait_s` to hand its memory back (a 190 GiB table is released -- and wiped by the driver --
+    asynchronously: a test that follows a big one at once would see a GPU that is still 'full' and skip for no reason)"""
+    import time
+    import torch
+    t0 = time.time()
+    while True:
+        free = torch.cuda.mem_get_info(0)[0]
+        if free >= want_bytes or time.time() - t0 > wait_s:
+            return free
+        time.sleep(0.5)

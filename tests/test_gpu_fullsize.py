@@ -148,7 +148,8 @@ def test_extended_table_w34():
     (expected 2 * 2^24 * 8 / 2^32 = 0.06 per tile)."""
     import pybsgs
     from pybsgs import ecpy
-    free, _ = torch.cuda.mem_get_info(0)
+    from conftest import free_hbm
+    free = free_hbm(200 * 2**30)
     if free < 200 * 2**30:
         pytest.skip("needs ~150 GiB of free HBM")
     wexp, htsz = 34, 31

@@ -158,7 +158,8 @@ def test_config3_style_w34_80bit_range(tmp_path):
     beyond the reference's file format).  The key sits 2^65 into the range so the test stays short."""
     import sys
     import torch
-    if torch.cuda.mem_get_info(0)[0] < 200 * 2**30:
+    from conftest import free_hbm
+    if free_hbm(200 * 2**30) < 200 * 2**30:
         pytest.skip("needs ~150 GiB of free HBM")
     sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
     from pybsgs import ecpy
@@ -274,7 +275,8 @@ def test_config4_true_flags_100_keys(tmp_path):
     import sys
     import time
     import torch
-    if torch.cuda.mem_get_info(0)[0] < 60 * 2**30:
+    from conftest import free_hbm
+    if free_hbm(60 * 2**30) < 60 * 2**30:
         pytest.skip("needs ~40 GiB of free HBM")
     sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
     from pybsgs import ecpy
@@ -311,7 +313,8 @@ def test_config5_style_two_engines_extended_table_120bit_range(tmp_path):
     sharing the dispenser.  (Config 5 proper is 8 GPUs with -w 34; one 288 GB GPU holds two engines at -w 33 -htsz 30.)"""
     import sys
     import torch
-    if torch.cuda.mem_get_info(0)[0] < 220 * 2**30:
+    from conftest import free_hbm
+    if free_hbm(220 * 2**30) < 220 * 2**30:
         pytest.skip("needs ~180 GiB of free HBM")
     sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
     from pybsgs import ecpy
