@@ -287,14 +287,13 @@ static double expected_overflow_entries(double lambda, unsigned cap, double buck
 }
 
 // `htsz` of the extended-table entry points: 1..31 = 2^htsz buckets (bucket = x & mask, like the reference's tables); a value above 31 IS the number of
-// buckets (any number below 2^32, 128-byte lines: the bucket comes from 48 bits of the key, giant_kernel.hip.h bucket_mul48) -- what lets a table fill the HBM there is (include/bsgs_hip.h)
+// buckets (any number below 2^32: the bucket then comes from 48 bits of the key, giant_kernel.hip.h bucket_mul48) -- what lets a table fill the HBM there is (include/bsgs_hip.h)
 static uint64_t ext_buckets(uint32_t htsz) { return htsz <= 31 ? 1ull << htsz : (uint64_t)htsz; }
 static uint32_t ext_bucket_mul(uint32_t htsz) { return htsz <= 31 || !(htsz & (htsz - 1)) ? 0u : htsz; }      // the bucket function follows from the bucket COUNT alone: a power of two -> the mask
 static int ext_check_args(uint64_t w, uint32_t htsz, uint32_t layout)
 {
     if (!w || w > (1ull << 36) || htsz < 1) return fail(BSGS_ERR_ARG, "need 0 < w <= 2^36 and htsz >= 1");
     if (layout != BSGS_TABLE_LINES64_LIST && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "layout must be BSGS_TABLE_LINES64_LIST or BSGS_TABLE_LINES128_LIST");
-    if (ext_bucket_mul(htsz) && layout != BSGS_TABLE_LINES128_LIST) return fail(BSGS_ERR_ARG, "a bucket count that is not 2^htsz needs BSGS_TABLE_LINES128_LIST (only the 128-byte-line kernels carry the multiplicative bucket function)");
     return BSGS_OK;
 }
 static int ext_check(bsgs_dev *d, uint64_t w, uint32_t htsz, uint32_t layout)
@@ -308,7 +307,10 @@ static uint64_t ext_list_capacity(uint64_t w, uint32_t htsz, uint32_t layout)
 {
     const unsigned cap_line = layout == BSGS_TABLE_LINES128_LIST ? 30 : 14;      // the last word of a full line is the bound of its overflow entries (OVERFLOW BOUND, support_kernels.hip.h)
     const double buckets = (double)ext_buckets(htsz);
-    return std::min<uint64_t>(w, (uint64_t)(1.25 * expected_overflow_entries((double)w / buckets, cap_line, buckets)) + (1u << 20));
+    // slack: 25 % for small tables; 5 % once the expectation is large (its relative spread is 1 / sqrt(entries), and the set built from it takes the next power of two above
+    // TWICE the capacity: at -w 35 on 3 * 2^30 lines of 64 bytes, 0.95 G expected entries, that is the difference between 16 and 32 GiB)
+    const double e = expected_overflow_entries((double)w / buckets, cap_line, buckets);
+    return std::min<uint64_t>(w, (uint64_t)((e > 1e8 ? 1.05 : 1.25) * e) + (1u << 20));
 }
 
 extern "C" int bsgs_ext_overflow_capacity(uint64_t w, uint32_t htsz, uint32_t layout, uint64_t *cap)

@@ -566,7 +566,6 @@ int bsgs_install_lines(bsgs_dev *d, u32x4 *lines, int lplog, u64 *ovf, uint64_t 
                        uint64_t overflow_buckets)
 {
     if (ht_items < 2 || ht_items >= (1ull << 32)) return fail(BSGS_ERR_ARG, "2 <= buckets < 2^32");
-    if ((ht_items & (ht_items - 1)) && lplog != 3) return fail(BSGS_ERR_ARG, "a bucket count that is not a power of two needs 128-byte lines");
     if (ovf) { int rc = validate_ext_table(d, lines, lplog, ovf, ovf_n, ht_items); if (rc) return rc; }
     free_table(d);
     d->lines = lines; d->lines_bytes = ht_items * (64ull << (lplog - 2));
@@ -759,7 +758,8 @@ static int launch_tiles(bsgs_dev *d, const fe *centres_dev, uint32_t ntiles, uin
     const size_t slot = l128 ? 8192 : 4096;
     const size_t lds = group > 1 ? (size_t)(bs / 64) * ((group == 4 ? (l128 ? slot : slot + 4096) : 2 * slot) + 2048) : 0;       // giant_pair2_kernel: REGION + 2 KiB of stash per wave
     const bool dbg = d->debug_flags != 0 || d->phase_probe;
-    if (d->layout == BSGS_TABLE_LINES64) HIPCHK(bsgs_launch_tile_lines64(A, grid, block, lds, st, group, dbg, &d->last_kernel));
+    if (d->layout == BSGS_TABLE_LINES64 && d->bucket_mul) HIPCHK(bsgs_launch_tile_lines64_any(A, grid, block, lds, st, group, dbg, &d->last_kernel));
+    else if (d->layout == BSGS_TABLE_LINES64) HIPCHK(bsgs_launch_tile_lines64(A, grid, block, lds, st, group, dbg, &d->last_kernel));
     else if (l128)                       HIPCHK(bsgs_launch_tile_lines128(A, grid, block, lds, st, group, dbg, &d->last_kernel));
     else { hipLaunchKernelGGL((giant_tile_kernel<0>), grid, block, 0, st, A); d->last_kernel = "giant_tile_kernel<0>"; }
     HIPCHK(hipGetLastError());
@@ -1415,7 +1415,8 @@ extern "C" int bsgs_table_lookup(bsgs_dev *d, const uint64_t *keys64, uint64_t n
     A.csr = d->csr; A.lines = d->lines; A.ovf = d->ovf; A.ovf_n = d->ovf_n; A.ht_items = d->ht_items; A.ht_mask = (u32)(d->ht_items - 1); A.bucket_mul = d->bucket_mul;
     hipError_t e = hipMemcpyAsync(dk, keys64, n * 8, hipMemcpyHostToDevice, d->stream);
     const dim3 grid((unsigned)((n + 63) / 64)), block(64);
-    if (d->layout == BSGS_TABLE_LINES64)       hipLaunchKernelGGL(table_lookup_kernel<2>, grid, block, 4096, d->stream, A, (const u64 *)dk, (u64)n, df);
+    if (d->layout == BSGS_TABLE_LINES64 && d->bucket_mul) hipLaunchKernelGGL(table_lookup_kernel<4>, grid, block, 4096, d->stream, A, (const u64 *)dk, (u64)n, df);
+    else if (d->layout == BSGS_TABLE_LINES64)  hipLaunchKernelGGL(table_lookup_kernel<2>, grid, block, 4096, d->stream, A, (const u64 *)dk, (u64)n, df);
     else if (d->layout == BSGS_TABLE_LINES128) hipLaunchKernelGGL(table_lookup_kernel<3>, grid, block, 8192, d->stream, A, (const u64 *)dk, (u64)n, df);
     else                                       hipLaunchKernelGGL(table_lookup_kernel<0>, grid, block, 0, d->stream, A, (const u64 *)dk, (u64)n, df);
     if (e == hipSuccess) e = hipGetLastError();

@@ -114,6 +114,7 @@ template <typename T> static inline hipError_t bsgs_big_malloc(T **p, size_t byt
 // tile_lines64.hip / tile_lines128.hip: the tile-kernel instantiations per bucket-line size (tile_launch.inc)
 hipError_t bsgs_launch_tile_lines64(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
 hipError_t bsgs_launch_tile_lines128(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
+hipError_t bsgs_launch_tile_lines64_any(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
 void bsgs_free_table(bsgs_dev *d);
 void bsgs_free_recv(bsgs_dev *d);                            // receive buffers that were never installed
 uint64_t bsgs_ovf_slots(uint64_t entries);                   // size of the overflow hash set for `entries` keys (power of two, load <= 1/2)

@@ -127,7 +127,7 @@ static void usage(const Config &c)
            "-transport   Several GPUs: rccl | peer (direct peer copies) | auto (RCCL when the GPUs are distinct and librccl loads)\n"
            "-lanes       -infile: public keys searched side by side, each on an engine of its own per GPU (default: 2 when a job is only a launch or two long, else 1)\n"
            "-w auto      The table Tune picks for the range given: the one that minimises table build + worst-case search (a 64-bit range: -w 30 -ext)\n"
-           "-buckets     Extended table: the number of buckets itself (any number below 2^32, 128-byte lines), e.g. -w 35 -buckets 1610612736; -htsz 30.585 says the same\n",
+           "-buckets     Extended table: the number of buckets itself (any number below 2^32; 64-byte lines up to 12.5 items per bucket, else 128-byte lines), e.g. -w 35 -buckets 3221225472\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
 }
 
@@ -509,15 +509,15 @@ static bsgs_dev *open_dev(int gpu)
     printf("GPU #%d %s memory %.0f/%.0f MB\n", gpu, name, fr / 1048576.0, tot / 1048576.0);
     return dev;
 }
-// the extended table's line size: 64-byte lines up to ~9 entries per bucket (the over-full 1 % go through the overflow set: measured faster AND half the memory of
-// 128-byte lines at -w 34 -htsz 31); beyond that, and for a bucket count that is not a power of two, 128-byte lines
+// the extended table's line size: 64-byte lines up to 12.5 entries per bucket on average -- at load 8 (-w 34 -htsz 31) one line in 120 is over-full, at 10.67 (-w 35 on
+// 3 * 2^30 lines) one in 13, and the probes that go on to the overflow set cost 4.5 % (40.2 -> 38.4 G; 37.1 G at load 12: profiles/r07k_*), still ahead of the 128-byte-line
+// kernel (35-36 G) at the same bytes of table --, 128-byte lines beyond that (up to ~24 per bucket) when they fit
 static uint32_t ext_layout(const Config &c, uint64_t free_bytes)
 {
     const uint64_t buckets = c.htsz_arg > 31 ? c.htsz_arg : 1ull << c.htsz_arg;
-    if (c.htsz_arg > 31) return BSGS_TABLE_LINES128_LIST;
     const double load = (double)c.w / (double)buckets;
     const bool fits128 = 128ull * buckets + (24ull << 30) < free_bytes;
-    return load > 9.0 && fits128 ? BSGS_TABLE_LINES128_LIST : BSGS_TABLE_LINES64_LIST;
+    return load > 12.5 && fits128 ? BSGS_TABLE_LINES128_LIST : BSGS_TABLE_LINES64_LIST;
 }
 static uint32_t transport_code(const Config &c) { return c.transport == "rccl" ? BSGS_TRANSPORT_RCCL : c.transport == "peer" ? BSGS_TRANSPORT_PEER : BSGS_TRANSPORT_AUTO; }
 static const char *transport_name(uint32_t t) { return t == BSGS_TRANSPORT_RCCL ? "RCCL over xGMI" : t == BSGS_TRANSPORT_PEER ? "peer copies" : "none"; }
@@ -583,8 +583,8 @@ static void load_engines(const Shared &S, const std::vector<int> &gpus, const st
         }
         uint32_t lay = 0; uint64_t bytes = 0, ovf = 0;
         CK(bsgs_table_info(devs[0], &lay, &bytes, &ovf));
-        printf("Extended table: %llu items, %.1f GiB in memory per GPU, %llu over-full buckets, %zu engine(s) ready in %.1fs\n", (unsigned long long)c.w, bytes / 1073741824.0,
-               (unsigned long long)ovf, n, secs());
+        printf("Extended table: %llu items in %llu lines of %d bytes, %.1f GiB in memory per GPU, %llu over-full buckets, %zu engine(s) ready in %.1fs\n", (unsigned long long)c.w,
+               (unsigned long long)(c.htsz_arg > 31 ? c.htsz_arg : 1ull << c.htsz_arg), layout == BSGS_TABLE_LINES128_LIST ? 128 : 64, bytes / 1073741824.0, (unsigned long long)ovf, n, secs());
         for (size_t gi = 0; gi < n; gi++) print_placement(gpus[gi], gi, devs[gi]);
     } else if (local) {
         per_gpu(gpus, [&](size_t gi) {
@@ -762,7 +762,8 @@ static TunePlan tune_plan(uint64_t free_bytes, double range_bits, int n_gpus, ui
         consider(k, (uint32_t)(k - 2), false, 68.0 * b + 4.0 * w, 8.2e9, 40e9, 12.0 * w);
     }
     for (int k = 24; k <= 34; k++) consider(k, (uint32_t)(k - 3), true, 64.0 * std::pow(2.0, k - 3) + 0.04 * std::pow(2.0, k), 11e9, k >= 33 ? 39e9 : 40e9, 0.0);      // extended, 64-byte lines, load 8
-    consider(35.0, 1610612736u, true, 128.0 * 1610612736.0 + 5.0 * 1073741824.0, 10e9, 33e9, 0.0);                                                                 // 1.5 * 2^30 lines of 128 bytes
+    consider(35.0, 1610612736u, true, 128.0 * 1610612736.0 + 5.0 * 1073741824.0, 10e9, 35e9, 0.0);                                                                 // 1.5 * 2^30 lines of 128 bytes (load 21.3 of 30)
+    consider(35.0, 3221225472u, true, 64.0 * 3221225472.0 + 17.0 * 1073741824.0, 7e9, 38e9, 0.0);                                                                  // 3 * 2^30 lines of 64 bytes (load 10.67 of 14) + a 16 GiB overflow set
     if (best.total_s > 1e299) { best = TunePlan{20.0, 18u, false, 0.0, 0.0, 0.0}; }
     return best;
 }

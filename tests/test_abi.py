@@ -173,7 +173,8 @@ def test_production_tile_kernels_do_not_spill(tmp_path):
     hipcc = "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    for tu, kernel, max_vgpr in (("tile_lines64.hip", "_Z18giant_pair2_kernelILi2ELb0ELb1EEv8TileArgs", 128), ("tile_lines128.hip", "_Z18giant_pair2_kernelILi3ELb0ELb1EEv8TileArgs", 168)):
+    for tu, kernel, max_vgpr in (("tile_lines64.hip", "_Z18giant_pair2_kernelILi2ELb0ELb1EEv8TileArgs", 128), ("tile_lines128.hip", "_Z18giant_pair2_kernelILi3ELb0ELb1EEv8TileArgs", 168),
+                                  ("tile_lines64_any.hip", "_Z18giant_pair2_kernelILi4ELb0ELb1EEv8TileArgs", 128)):
         asm = tmp_path / (tu + ".s")
         subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only", "-o", str(asm),
                                os.path.join(ROOT, "bsgs-cuda_amd", "csrc", tu)], stderr=subprocess.DEVNULL)

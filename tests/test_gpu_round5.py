@@ -25,7 +25,7 @@ def _centres(w, maxnonce):
     return ms, [ecpy.mul(m % N) for m in ms]
 
 
-@pytest.mark.parametrize("w,htsz,layout", [(1 << 20, 14, 4), (1 << 20, 13, 5), ((1 << 20) + 777, 12288, 5), (3 << 19, 15, 4)])
+@pytest.mark.parametrize("w,htsz,layout", [(1 << 20, 14, 4), (1 << 20, 13, 5), ((1 << 20) + 777, 12288, 5), (3 << 19, 15, 4), (1 << 20, 98306, 4)])
 def test_three_startup_strategies_give_byte_identical_tables_on_two_engines(w, htsz, layout):
     """bsgs_startup_ext_tables with two engines of one process (both on GPU 0: peer copies; RCCL refuses one GPU listed twice): BROADCAST, LOCAL and
     ALLGATHER must leave BOTH engines with the same table -- equal position-dependent checksums across engines AND across strategies (the direct builder
@@ -64,6 +64,8 @@ def test_three_startup_strategies_give_byte_identical_tables_on_two_engines(w, h
             assert c["total"] == w and c["malformed_lines"] == 0 and c["unsorted_lines"] == 0, (strategy, c)
             got, ng, _ = d.run(centres, 65536)
             assert (ng, got) == (nw, want), strategy
+            if layout == 4 and htsz > 31:                               # 64-byte lines, a bucket count that is no power of two: the kernels of their own
+                assert d.last_kernel() == "giant_pair2_kernel<4, false, true>"
             assert d.table_owned()
         seen[strategy] = sums[0]
         for d in devs:
@@ -194,9 +196,11 @@ def test_host_extended_table_with_any_number_of_buckets(tmp_path):
     x, y = ecpy.mul(key)
     geo = ["-t", "64", "-b", "8", "-p", "16", "-pb", "%02x%064x" % (2 + (y & 1), x), "-pk", "1", "-pke", "ffffff", "-w", "18"]
     r = _host(geo + ["-buckets", "12289"], tmp_path)
-    assert r.returncode == 0 and "KEY[1]: 0x" + "%064x" % key in r.stdout and "12289 buckets (not a power of two)" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+    assert r.returncode == 0 and "KEY[1]: 0x" + "%064x" % key in r.stdout and "12289 buckets (not a power of two)" in r.stdout and "12289 lines of 128 bytes" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
     r = _host(geo + ["-htsz", "13.585"], tmp_path)
     assert r.returncode == 0 and "KEY[1]: 0x" + "%064x" % key in r.stdout and "buckets (extended table)" in r.stdout
+    r = _host(geo + ["-buckets", "24577"], tmp_path)                                  # load 10.67: 64-byte lines (the host's rule: up to 12.5 per bucket)
+    assert r.returncode == 0 and "KEY[1]: 0x" + "%064x" % key in r.stdout and "24577 lines of 64 bytes" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
     r = _host(geo + ["-buckets", "8192", "-sf", "1"], tmp_path)
     assert r.returncode == 0 and "KEY[1]: 0x" + "%064x" % key in r.stdout and "Search in file" in r.stdout and "not a power of two" not in r.stdout
 
