@@ -816,6 +816,32 @@ static void save_checkpoint(Shared &S)
     rename(tmp.c_str(), dst.c_str());
 }
 
+// ---- the reference's limits on -w / -htsz for tables in ITS format (1_9_7File.pb:4412-4472): -w below 3069485951, -htsz below 32, and the "UNSAFE mode" question
+// (answer Y on stdin to go on) where duplicate 32-bit values in one bucket become likely; then its warning about a -htsz that is too low.  Extended tables
+// (built in GPU memory, no HT files: -ext, -w above 2^32, -buckets) are outside that format and outside these limits.  Returns "" to go on, else the exit message.
+static std::string table_limits(uint64_t w, uint32_t htsz, FILE *answers)
+{
+    if (w >= 3069485951ull) return "-w should be less or equil to 3069485951 Or 2^31.515349920643907";
+    if (htsz > 31) return "-htsz should be less than 32";
+    static const struct { uint32_t htsz; uint64_t limit; const char *shown; } unsafe[] = {
+        {27, 1331331443ull, "1331331443 or 2^30.310222637591963"}, {28, 1777178603ull, "1777178603 Or 2^30.726941530690112"}, {29, 3069485951ull, "3069485950 Or 2^31.515349920643907"},
+        {30, 3069485951ull, "3069485951 Or 2^31.515349920643907"}, {31, 3069485951ull, "3069485951 Or 2^31.515349920643907"}};
+    for (const auto &u : unsafe)
+        if (htsz == u.htsz && w > u.limit) {
+            printf("With -htsz %u value -w should be less or equil to %s\nDue to the possibility of duplicate values in the hash table\n"
+                   "It is unsafe to use values higher than those specified above\nTo continue in UNSAFE mode type Y and press ENTER\n", u.htsz, u.shown);
+            fflush(stdout);
+            char line[64] = {0};
+            if (!answers || !fgets(line, sizeof line, answers)) return " ";
+            std::string ans(line);
+            while (!ans.empty() && (ans.back() == '\n' || ans.back() == '\r')) ans.pop_back();
+            if (ans != "Y") return " ";
+        }
+    const int need = (int)std::floor(std::log2((double)w)) - (int)htsz;
+    if (need > 3) printf("WARNING! -htsz parametr is to low, should be at least %d\n", (int)std::floor(std::log2((double)w)) - 2);
+    return "";
+}
+
 // ---- -selftest: the host-side logic that needs no GPU (CPU test tier, tests/test_host_logic.py) ------------------------
 // prints "key value" lines: SHA1, the configuration fingerprint, host EC arithmetic, public-key parsing, the dispenser
 // sequence and the table-free resolver, each for the inputs given on the command line
@@ -874,6 +900,10 @@ static int selftest(int argc, char **argv)
             const TunePlan pl = tune_plan(fr, atof(a[i + 2].c_str()), atoi(a[i + 3].c_str()), 1ull << 24);
             i += 3;
             printf("plan %s | w %.2f htsz %u ext %d build %.3f search %.3f total %.3f\n", plan_flags(pl).c_str(), pl.w_log2, pl.htsz_arg, pl.ext ? 1 : 0, pl.build_s, pl.search_s, pl.total_s);
+        } else if (a[i] == "limits" && i + 2 < a.size()) {                    // w (decimal), htsz: the reference's -w / -htsz limits and UNSAFE question (answer on stdin)
+            const std::string m = table_limits(strtoull(a[i + 1].c_str(), nullptr, 10), (uint32_t)atoi(a[i + 2].c_str()), stdin);
+            i += 2;
+            printf("limits %s\n", m.empty() ? "ok" : m == " " ? "exit" : m.c_str());
         } else if (a[i] == "checkpoint" && i + 1 < a.size()) {                // next counter, then in-flight counters ("-" = idle GPU): the saved one
             Shared S;
             if (!hs::fe_from_hex(S.glob_key, a[++i])) return 2;
@@ -916,6 +946,7 @@ int main(int argc, char **argv)
     stage("runtime + device discovery");
     for (int g : gpus) tune(g);
     stage("Tune lines (open / close every GPU)");
+    if (!c.ext && !c.w_auto) { const std::string m = table_limits(c.w, c.htsz_arg, stdin); if (!m.empty()) die(m == " " ? "" : m); }
     // ---- range (1_9_7File.pb:4887-4943)
     if (!hs::fe_from_hex(S.start, c.pk) || hs::fe_is_zero(S.start)) die("Start range can`t be zero");
     printf("START RANGE= %s\n", hs::fe_to_hex(S.start).c_str());

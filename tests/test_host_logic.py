@@ -136,3 +136,30 @@ def test_checkpoint_is_the_minimum_in_flight_counter():
     assert selftest("checkpoint", "0901", "0301", "-", "0601")[0] == ["save", "%064x" % 0x301]
     assert selftest("checkpoint", "0901", "-", "-")[0] == ["save", "%064x" % 0x901]
     assert selftest("checkpoint", "0901", "0a01", "0b01")[0] == ["save", "%064x" % 0x901]
+
+
+def test_reference_table_limits_and_unsafe_question():
+    """the reference's limits on -w / -htsz for tables in its format and its UNSAFE-mode question (1_9_7File.pb:4412-4472): -w below 3069485951, -htsz below 32,
+    "type Y" above the per--htsz duplicate limits (27: 1331331443, 28: 1777178603), and the "-htsz parametr is to low" warning (log2(w) - htsz > 3)."""
+    if not os.path.exists(EXE):
+        pytest.skip("host binary not built (run __graft_entry__.build())")
+
+    def limits(w, htsz, answer=""):
+        r = subprocess.run([EXE, "-selftest", "limits", str(w), str(htsz)], input=answer, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        return r.stdout
+
+    assert limits(1 << 30, 28).splitlines() == ["limits ok"]                                   # BASELINE config 4's table
+    assert "limits -w should be less or equil to 3069485951" in limits(3069485951, 29)
+    assert limits(3069485950, 29).splitlines()[-1] == "limits ok"
+    assert "limits -htsz should be less than 32" in limits(1 << 20, 32)
+    for htsz, lim in ((27, 1331331443), (28, 1777178603)):
+        assert limits(lim, htsz).splitlines()[-1] == "limits ok" and "UNSAFE" not in limits(lim, htsz)
+        out = limits(lim + 1, htsz, "Y\n")
+        assert "With -htsz %d value -w should be less or equil to %d" % (htsz, lim) in out and "To continue in UNSAFE mode type Y and press ENTER" in out
+        assert out.splitlines()[-1] == "limits ok"
+        for answer in ("n\n", "y\n", "", "Yes\n"):
+            assert limits(lim + 1, htsz, answer).splitlines()[-1] == "limits exit", answer
+    out = limits(1 << 30, 26)                                                                    # 30 - 26 > 3
+    assert "WARNING! -htsz parametr is to low, should be at least 28" in out and out.splitlines()[-1] == "limits ok"
+    assert "WARNING" not in limits(1 << 30, 27)
