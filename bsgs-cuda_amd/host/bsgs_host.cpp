@@ -127,7 +127,7 @@ static void usage(const Config &c)
            "-transport   Several GPUs: rccl | peer (direct peer copies) | auto (RCCL when the GPUs are distinct and librccl loads)\n"
            "-lanes       -infile: public keys searched side by side, each on an engine of its own per GPU (default: 2 when a job is only a launch or two long, else 1)\n"
            "-w auto      The table Tune picks for the range given: the one that minimises table build + worst-case search (a 64-bit range: -w 30 -ext)\n"
-           "-buckets     Extended table: the number of buckets itself (any number below 2^32; 64-byte lines up to 12.5 items per bucket, else 128-byte lines), e.g. -w 35 -buckets 1610612736\n",
+           "-buckets     Extended table: the number of buckets itself (any number below 2^32; 64-byte lines up to 12.5 items per bucket, else 128-byte lines), e.g. -w 35 -buckets 3221225472\n",
            c.t, c.b, c.p, c.pk.c_str(), c.htsz, c.wt);
 }
 
@@ -510,9 +510,9 @@ static bsgs_dev *open_dev(int gpu)
     return dev;
 }
 // the extended table's line size: 64-byte lines up to 12.5 entries per bucket on average -- at load 8 (-w 34 -htsz 31) one line in 120 is over-full, at 10.67 one in 13,
-// and on 128 GiB of lines the probes that go on to the overflow set cost 4.5 % (load 10.67) to 8 % (load 12), still ahead of the 128-byte-line kernel on the same bytes of table
-// (profiles/r07m_fuller_lines.log) --, 128-byte lines beyond that (up to ~24 per bucket) when they fit.  NOT a rule for filling the HBM: at 192 GiB the 64-byte lines lose
-// (-w 35: 28.5 G on 3 * 2^30 lines of 64 bytes against 35.2 G on 1.5 * 2^30 lines of 128 bytes, profiles/r07l_*), which is why Tune names the bucket count itself there
+// and the probes that go on to the overflow set cost 4.3 % (load 10.67) to 7 % (load 12) on 128 GiB of lines (39.6 -> 37.9 -> 36.8 G, profiles/r07m_fuller_lines.log), still
+// level with or ahead of the 128-byte-line kernel on the same bytes of table (36.7 G at 1.5 * 2^34 items, 35.7 G at 2^35 where the 64-byte lines do 36.9 G: r07m, r07n) --,
+// 128-byte lines beyond that (up to ~24 per bucket) when they fit
 static uint32_t ext_layout(const Config &c, uint64_t free_bytes)
 {
     const uint64_t buckets = c.htsz_arg > 31 ? c.htsz_arg : 1ull << c.htsz_arg;
@@ -763,8 +763,8 @@ static TunePlan tune_plan(uint64_t free_bytes, double range_bits, int n_gpus, ui
         consider(k, (uint32_t)(k - 2), false, 68.0 * b + 4.0 * w, 8.2e9, 40e9, 12.0 * w);
     }
     for (int k = 24; k <= 34; k++) consider(k, (uint32_t)(k - 3), true, 64.0 * std::pow(2.0, k - 3) + 0.04 * std::pow(2.0, k), 11e9, k >= 33 ? 39e9 : 40e9, 0.0);      // extended, 64-byte lines, load 8
-    consider(35.0, 1610612736u, true, 128.0 * 1610612736.0 + 5.0 * 1073741824.0, 10e9, 35e9, 0.0);                                                                 // 1.5 * 2^30 lines of 128 bytes (load 21.3 of 30)
-    consider(35.0, 3221225472u, true, 64.0 * 3221225472.0 + 17.0 * 1073741824.0, 6.1e9, 28.5e9, 0.0);                                                               // 3 * 2^30 lines of 64 bytes (load 10.67 of 14) + a 16 GiB overflow set: measured SLOWER than the line above (28.5 G, 32.9 G on 2.75 * 2^30 lines: profiles/r07l_*)
+    consider(35.0, 1610612736u, true, 128.0 * 1610612736.0 + 5.0 * 1073741824.0, 8.5e9, 35.7e9, 0.0);                                                               // 1.5 * 2^30 lines of 128 bytes (load 21.3 of 30)
+    consider(35.0, 3221225472u, true, 64.0 * 3221225472.0 + 17.0 * 1073741824.0, 8.2e9, 36.8e9, 0.0);                                                                // 3 * 2^30 lines of 64 bytes (load 10.67 of 14) + a 16 GiB overflow set: 36.7-37.1 G against 35.7-35.8 G on one box (profiles/r07n_*)
     if (best.total_s > 1e299) { best = TunePlan{20.0, 18u, false, 0.0, 0.0, 0.0}; }
     return best;
 }

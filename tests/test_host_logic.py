@@ -108,7 +108,7 @@ def test_tune_advice_for_mi355x():
 def test_tune_plan_for_a_range():
     """Tune for a RANGE (the reference's Tune, 1_9_7File.pb:324-431, knows the GPU only): the table that minimises build + worst-case search.
     A 64-bit range wants a table of 2^30..2^31 points built in GPU memory (no files to bring to the host: 0.3 s all in), an 80-bit range the largest table one
-    GPU holds (-w 35 on 1.5 * 2^30 bucket lines of 128 bytes), a small GPU stays within its memory, more GPUs shorten the search and never shrink the table."""
+    GPU holds (-w 35 on 3 * 2^30 bucket lines of 64 bytes), a small GPU stays within its memory, more GPUs shorten the search and never shrink the table."""
     def plan(free, bits, gpus):
         o = selftest("plan", free, bits, gpus)[0]
         f = o[o.index("|") + 1:]
@@ -117,7 +117,7 @@ def test_tune_plan_for_a_range():
     p64 = plan(big, 64, 1)
     assert p64["ext"] and 30 <= p64["w"] <= 31 and p64["total"] < 0.4 and p64["flags"].endswith("-ext")
     p80 = plan(big, 80, 1)
-    assert p80["w"] == 35 and p80["htsz"] == 1610612736 and "-buckets 1610612736" in p80["flags"] and p80["search"] < 600
+    assert p80["w"] == 35 and p80["htsz"] == 3221225472 and "-buckets 3221225472" in p80["flags"] and p80["search"] < 600
     p120 = plan(big, 120, 8)
     assert p120["w"] == 35 and abs(p120["search"] / plan(big, 120, 1)["search"] - 1 / 8) < 1e-3
     small = plan(25 * 10**9, 64, 1)
