@@ -162,12 +162,18 @@ int bsgs_fabric_broadcast(bsgs_fabric *f, void *const *bufs, size_t bytes, int r
         const size_t piece = 4ull << 30;                         // one collective per 4 GiB: every call's count stays far from any 32-bit limit inside the library
         for (size_t off = 0; off < bytes; off += piece) {
             const size_t cnt = std::min(piece, bytes - off);
+            // a group that was started is always ended, also when a call inside it fails (the first failure is the one reported)
             NCCLCHK(f, R.GroupStart());
-            for (int i = 0; i < n; i++) {
-                HIPCHK(hipSetDevice(f->devs[i]->id));
-                NCCLCHK(f, R.Broadcast((const char *)bufs[i] + off, (char *)bufs[i] + off, cnt, ncclUint8, root, f->comms[i], f->devs[i]->stream));
+            ncclResult_t bad = ncclSuccess;
+            hipError_t hbad = hipSuccess;
+            for (int i = 0; i < n && bad == ncclSuccess && hbad == hipSuccess; i++) {
+                hbad = hipSetDevice(f->devs[i]->id);
+                if (hbad == hipSuccess) bad = R.Broadcast((const char *)bufs[i] + off, (char *)bufs[i] + off, cnt, ncclUint8, root, f->comms[i], f->devs[i]->stream);
             }
-            NCCLCHK(f, R.GroupEnd());
+            const ncclResult_t ge = R.GroupEnd();
+            HIPCHK(hbad);
+            NCCLCHK(f, bad);
+            NCCLCHK(f, ge);
         }
     } else {
         for (int i = 0; i < n; i++) {
@@ -185,12 +191,20 @@ int bsgs_fabric_allgather(bsgs_fabric *f, void *const *bufs, size_t slice_bytes)
     if (!slice_bytes || (n == 1 && !f->rccl)) return fabric_sync(f);
     if (f->rccl) {                                                // (one rank: the collective is still issued -- in place, nothing moves -- so that a one-GPU lease exercises the call)
         RcclApi &R = rccl_api();
+        // counted in 64-bit words where the slice allows (line slices always do): the element count of a 24 GiB slice (-w 35 over 8 GPUs) stays below 2^32
+        const bool wide = slice_bytes % 8 == 0;
         NCCLCHK(f, R.GroupStart());
-        for (int i = 0; i < n; i++) {
-            HIPCHK(hipSetDevice(f->devs[i]->id));
-            NCCLCHK(f, R.AllGather((const char *)bufs[i] + (size_t)i * slice_bytes, bufs[i], slice_bytes, ncclUint8, f->comms[i], f->devs[i]->stream));
+        ncclResult_t bad = ncclSuccess;
+        hipError_t hbad = hipSuccess;
+        for (int i = 0; i < n && bad == ncclSuccess && hbad == hipSuccess; i++) {
+            hbad = hipSetDevice(f->devs[i]->id);
+            if (hbad == hipSuccess)
+                bad = R.AllGather((const char *)bufs[i] + (size_t)i * slice_bytes, bufs[i], wide ? slice_bytes / 8 : slice_bytes, wide ? ncclUint64 : ncclUint8, f->comms[i], f->devs[i]->stream);
         }
-        NCCLCHK(f, R.GroupEnd());
+        const ncclResult_t ge = R.GroupEnd();
+        HIPCHK(hbad);
+        NCCLCHK(f, bad);
+        NCCLCHK(f, ge);
     } else {
         for (int i = 0; i < n; i++) {
             HIPCHK(hipSetDevice(f->devs[i]->id));

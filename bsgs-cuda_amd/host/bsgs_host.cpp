@@ -1150,7 +1150,7 @@ int main(int argc, char **argv)
             bool resumed = false;
             {
                 std::lock_guard<std::mutex> lk(lane_mutex);
-                while (next_job < pubs.size() && recovery && (int)next_job + 1 != rec_pos) { outs[next_job].done = true; next_job++; }      // -wl: everything before the saved position is skipped
+                while (next_job < pubs.size() && recovery && (int)next_job + 1 != rec_pos) { { std::lock_guard<std::mutex> lo(out_mutex); outs[next_job].done = true; } next_job++; }      // -wl: everything before the saved position is skipped
                 if (next_job >= pubs.size()) { lane_listpos[l] = 0; break; }
                 li = next_job++;
                 lane_listpos[l] = (int)li + 1;
