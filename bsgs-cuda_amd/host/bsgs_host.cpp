@@ -81,6 +81,7 @@ struct Config {
     std::string infile, recovery_file;
     int wt = 180;
     bool onlygen = false;                          // onlygen_1_9_6File0.exe behaviour: build files and exit
+    bool cpugen = false;                           // -cpugen: table and giants files built on the host CPU (with -onlygen: no GPU is touched at all)
     uint64_t max_tiles = 0;                        // test hook: stop after this many tiles (0 = unlimited)
     bool ext = false;                              // extended table (bucket lines + overflow list, no HT files); implied by w >= 3069485951
     std::string dir = ".";                         // where table / output files live
@@ -116,7 +117,7 @@ static void usage(const Config &c)
            "-pk      Range start from , default %s\n-pke     End range \n-w       Set number of baby items 2^ or decimal representation\n"
            "-htsz    Set number of HashTable 2^ , default %u\n-infile  Set file with pubkey for searching in uncompressed/compressed  format (search sequential)\n"
            "-wl      Set recovery file from which the state will be loaded\n-wt      Set timer for autosaving current state, default every %dseconds\n"
-           "-onlygen Generate the table files and exit (onlygen_1_9_6File0.exe)\n-dir     Directory for table files, currentwork.txt and win.txt\n"
+           "-onlygen Generate the table files and exit (onlygen_1_9_6File0.exe)\n-cpugen  Build missing table / giants files on the host CPU; with -onlygen no GPU is touched (the reference`s CPU-only generator)\n-dir     Directory for table files, currentwork.txt and win.txt\n"
            "-ext     Extended baby table built in GPU memory (no HT files); automatic for -w above the reference limit, up to 2^36\n"
            "-noverify    Several GPUs: skip the comparison of the replicas (table checksums, one probe tile) after they were made\n"
            "-refquirks   Reproduce the reference kernel's -Gy borrow bug bit for bit (default: correct arithmetic, finds a superset)\n"
@@ -172,6 +173,7 @@ static Config parse_args(int argc, char **argv)
         else if (a == "-wl") { c.recovery_file = next(); printf("Recovery work file: %s\n", c.recovery_file.c_str()); }
         else if (a == "-wt") { c.wt = std::max(30, atoi(next().c_str())); printf("Saving timer every %d seconds\n", c.wt); }
         else if (a == "-onlygen") c.onlygen = true;
+        else if (a == "-cpugen") c.cpugen = true;
         else if (a == "-maxtiles") c.max_tiles = strtoull(next().c_str(), nullptr, 10);
         else if (a == "-dir") c.dir = next();
         else if (a == "-ext") c.ext = true;
@@ -816,6 +818,68 @@ static void save_checkpoint(Shared &S)
     rename(tmp.c_str(), dst.c_str());
 }
 
+// ---- -cpugen: the table and giants files built on the HOST CPU (BASELINE config 1 as it is worded; the reference's CPU-only generator is a program of its own,
+// onlygen1_9_6File.pb:2915-3204, over lib/Curve64.pb).  Plumbing, not a fast path: k*G for k = 1..w by affine additions with batched normalisation (host_secp.h), one
+// range of k per host thread; entries filed by bucket (counting sort), each bucket ascending by (hash, position) -- the order of the reference's sorted buckets
+// (1_9_7File.pb:2771-2820) and of the GPU builder; images as in SURVEY.md Appendix C (1_9_7File.pb:3232-3444).  Byte-identical to the GPU builder's files (CPU test).
+static void cpu_build_tables(uint64_t w, uint32_t htsz, uint8_t *htgpu, uint8_t *htcpu)
+{
+    const uint64_t items = 1ull << htsz;
+    std::vector<uint64_t> key(w);                                     // low 64 bits of x(k*G) at index k - 1
+    const unsigned nth = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max(1u, std::thread::hardware_concurrency()), 64ull, (w + 65535) / 65536}));
+    std::vector<std::thread> th;
+    for (unsigned q = 0; q < nth; q++) th.emplace_back([&, q]() {
+        const uint64_t lo = w * q / nth, hi = w * (q + 1) / nth;      // k - 1 in [lo, hi)
+        for (uint64_t first = lo; first < hi; first += 65536) {
+            const size_t cnt = (size_t)std::min<uint64_t>(65536, hi - first);
+            const std::vector<Affine> pts = hs::strided_multiples(hs::G, first + 1, 1, cnt);
+            for (size_t i = 0; i < cnt; i++) key[first + i] = pts[i].x.l[0];
+        }
+    });
+    for (auto &t : th) t.join();
+    std::vector<uint32_t> off(items + 1, 0);
+    for (uint64_t i = 0; i < w; i++) off[((uint32_t)key[i] & (uint32_t)(items - 1)) + 1]++;
+    for (uint64_t b = 0; b < items; b++) off[b + 1] += off[b];       // off[b] = entries in buckets below b
+    std::vector<uint64_t> ent(w);                                     // hash << 32 | position: ascending = (hash, position)
+    {
+        std::vector<uint32_t> cur(off.begin(), off.end() - 1);
+        for (uint64_t i = 0; i < w; i++) ent[cur[(uint32_t)key[i] & (uint32_t)(items - 1)]++] = (key[i] >> 32 << 32) | i;
+    }
+    for (uint64_t b = 0; b < items; b++) std::sort(ent.begin() + off[b], ent.begin() + off[b + 1]);
+    uint32_t *g = (uint32_t *)htgpu, *c = (uint32_t *)htcpu;
+    memcpy(g, off.data(), 4 * (items + 1));                           // starts, then the total (= w)
+    memcpy(c, off.data(), 4 * (items + 1));
+    for (uint64_t i = 0; i < w; i++) {
+        g[items + 1 + i] = (uint32_t)(ent[i] >> 32);
+        c[items + 1 + 2 * i] = (uint32_t)(ent[i] >> 32);
+        c[items + 1 + 2 * i + 1] = (uint32_t)ent[i];
+    }
+}
+// G2[i] = (i + 1) * A, i < t*b*p, in the strided file layout (1_9_7File.pb:1831-1903, 1954-1970): the k-th MOST significant 32-bit word of coordinate c of G2[i]
+// at u32 index c*8*maxnonce + ((i % p)*8 + k)*T + i / p, T = t*b
+static void cpu_build_g2(const Affine &A, uint32_t t, uint32_t b, uint32_t p, uint8_t *g2)
+{
+    const uint64_t T = (uint64_t)t * b, maxnonce = T * p;
+    uint32_t *out = (uint32_t *)g2;
+    const unsigned nth = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)std::max(1u, std::thread::hardware_concurrency()), 64ull, (maxnonce + 65535) / 65536}));
+    std::vector<std::thread> th;
+    for (unsigned q = 0; q < nth; q++) th.emplace_back([&, q]() {
+        const uint64_t lo = maxnonce * q / nth, hi = maxnonce * (q + 1) / nth;
+        for (uint64_t first = lo; first < hi; first += 65536) {
+            const size_t cnt = (size_t)std::min<uint64_t>(65536, hi - first);
+            const std::vector<Affine> pts = hs::strided_multiples(A, first + 1, 1, cnt);
+            for (size_t j = 0; j < cnt; j++) {
+                const uint64_t i = first + j;
+                for (int c = 0; c < 2; c++) {
+                    const hs::Fe &v = c ? pts[j].y : pts[j].x;
+                    for (int k = 0; k < 8; k++) out[(uint64_t)c * 8 * maxnonce + ((i % p) * 8 + k) * T + i / p] = (uint32_t)(v.l[3 - k / 2] >> (32 * (1 - k % 2)));
+                }
+            }
+        }
+    });
+    for (auto &x : th) x.join();
+}
+
 // ---- the reference's limits on -w / -htsz for tables in ITS format (1_9_7File.pb:4412-4472): -w below 3069485951, -htsz below 32, and the "UNSAFE mode" question
 // (answer Y on stdin to go on) where duplicate 32-bit values in one bucket become likely; then its warning about a -htsz that is too low.  Extended tables
 // (built in GPU memory, no HT files: -ext, -w above 2^32, -buckets) are outside that format and outside these limits.  Returns "" to go on, else the exit message.
@@ -936,13 +1000,16 @@ int main(int argc, char **argv)
         printf("[startup] %-44s %.3fs\n", what, std::chrono::duration<double>(n - t_stage).count());
         t_stage = n;
     };
+    const bool cpu_only = c.cpugen && c.onlygen;                      // the reference's CPU-only generator: no GPU is looked for, none is needed
+    if (c.cpugen && (c.ext || c.w_auto)) die("-cpugen builds files in the reference`s format: not with -ext / -w auto / -w above 3069485950");
     int ngpu = 0;
-    CK(bsgs_dev_count(&ngpu));
-    if (ngpu <= 0) die("No GPU found");
     std::vector<int> gpus;
-    if (c.devices.empty()) for (int i = 0; i < ngpu; i++) gpus.push_back(i);
-    else { std::stringstream ss(c.devices); std::string tok; while (std::getline(ss, tok, ',')) gpus.push_back(atoi(tok.c_str())); }
-
+    if (!cpu_only) {
+        CK(bsgs_dev_count(&ngpu));
+        if (ngpu <= 0) die("No GPU found");
+        if (c.devices.empty()) for (int i = 0; i < ngpu; i++) gpus.push_back(i);
+        else { std::stringstream ss(c.devices); std::string tok; while (std::getline(ss, tok, ',')) gpus.push_back(atoi(tok.c_str())); }
+    }
     stage("runtime + device discovery");
     for (int g : gpus) tune(g);
     stage("Tune lines (open / close every GPU)");
@@ -965,7 +1032,7 @@ int main(int argc, char **argv)
     S.start_neg = hs::affine_neg(hs::point_mul(hs::G, S.start));
     int range_bits = 0;
     if (S.end_range) for (int l = 3; l >= 0 && !range_bits; l--) if (S.width.l[l]) range_bits = 64 * l + 64 - __builtin_clzll(S.width.l[l]);
-    if (range_bits) {
+    if (range_bits && !cpu_only) {
         // Tune for THIS range (the reference's Tune, 1_9_7File.pb:324-431, knows the GPU only): the table that minimises build + worst-case search
         bsgs_dev *dt = nullptr;
         uint64_t fr = 0, tot = 0;
@@ -1008,10 +1075,11 @@ int main(int argc, char **argv)
     if (c.ext) printf("Extended table: %llu items, built in GPU memory at start-up (no HT files)\n", (unsigned long long)c.w);
     else if (read_file(f_gpu, htgpu, gpu_bytes) && read_file(f_cpu, tables.htcpu, cpu_bytes)) printf("Both HT files exist\n");
     else {
-        printf("Generate HT with %llu items on the GPU\n", (unsigned long long)c.w);
+        printf("Generate HT with %llu items on the %s\n", (unsigned long long)c.w, c.cpugen ? "host CPU" : "GPU");
         const auto t0 = std::chrono::steady_clock::now();
         htgpu.resize(gpu_bytes); tables.htcpu.resize(cpu_bytes);
-        CK(bsgs_build_baby_tables(dev0(), c.w, c.htsz, htgpu.data(), tables.htcpu.data(), BSGS_NO_INSTALL));
+        if (c.cpugen) cpu_build_tables(c.w, c.htsz, htgpu.data(), tables.htcpu.data());
+        else CK(bsgs_build_baby_tables(dev0(), c.w, c.htsz, htgpu.data(), tables.htcpu.data(), BSGS_NO_INSTALL));
         writers.emplace_back([&]() { write_file(f_cpu, tables.htcpu.data(), cpu_bytes); });
         writers.emplace_back([&]() { write_file(f_gpu, htgpu.data(), gpu_bytes); });
         printf("Done in %.1fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -1019,11 +1087,14 @@ int main(int argc, char **argv)
     if (read_file(f_g2, g2, g2_bytes)) printf("Load BIN file:%s\n", f_g2.c_str());
     else {
         printf("Generate Giants Buffer: %llu items\n", (unsigned long long)S.maxnonce);
-        uint8_t axy[64];
-        hs::affine_to_le(S.addpubg, axy, axy + 32);
-        CK(bsgs_generate_g2(dev0(), axy, c.t, c.b, c.p));
         g2.resize(g2_bytes);
-        CK(bsgs_download_g2(dev0(), g2.data(), g2_bytes));
+        if (c.cpugen) cpu_build_g2(S.addpubg, c.t, c.b, c.p, g2.data());
+        else {
+            uint8_t axy[64];
+            hs::affine_to_le(S.addpubg, axy, axy + 32);
+            CK(bsgs_generate_g2(dev0(), axy, c.t, c.b, c.p));
+            CK(bsgs_download_g2(dev0(), g2.data(), g2_bytes));
+        }
         writers.emplace_back([&]() { write_file(f_g2, g2.data(), g2_bytes); });
         saved_msg = "Save BIN file:" + f_g2 + "\n";                  // printed once the file IS on disk (flush_writers)
     }

@@ -163,3 +163,37 @@ def test_reference_table_limits_and_unsafe_question():
     out = limits(1 << 30, 26)                                                                    # 30 - 26 > 3
     assert "WARNING! -htsz parametr is to low, should be at least 28" in out and out.splitlines()[-1] == "limits ok"
     assert "WARNING" not in limits(1 << 30, 27)
+
+
+def test_onlygen_on_the_host_cpu_config1_and_small_fixture(tmp_path):
+    """BASELINE config 1 as it is worded -- "onlygen baby-step table build -w 20 -htsz 18 on host CPU (plumbing, no GPU; bit-exact vs the reference htCPU file)":
+    `bsgs_mi355x -onlygen -cpugen` builds htGPU / htCPU / g2 with the host's own EC arithmetic, touches no GPU (this test runs in the CPU tier) and writes the
+    reference's file names and bytes (sha256 from the plain-Python generator, tests/golden/gen_golden.py; formats: 1_9_7File.pb:3232-3444, 1831-1903; the reference's
+    CPU-only generator: onlygen1_9_6File.pb:2915-3204).  Then the small fixture's geometry (-w 10 -htsz 8 -t 2 -b 2 -p 4): byte for byte the fixture's images."""
+    import json
+    if not os.path.exists(EXE):
+        pytest.skip("host binary not built (run __graft_entry__.build())")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")                    # even on a GPU box: nothing to find
+    with open(os.path.join(ROOT, "tests", "golden", "cfg1_digests.json")) as f:
+        d = json.load(f)
+    args = ["-onlygen", "-cpugen", "-dir", str(tmp_path), "-t", str(d["g2_t"]), "-b", str(d["g2_b"]), "-p", str(d["g2_p"]), "-w", "20", "-htsz", "18"]
+    r = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "Generate HT with 1048576 items on the host CPU" in r.stdout and "onlygen: files ready" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    for name, size, sha in ((d["htgpu_name"], d["htgpu_size"], d["htgpu_sha256"]), (d["htcpu_name"], d["htcpu_size"], d["htcpu_sha256"]), (d["g2_name"], d["g2_size"], d["g2_sha256"])):
+        blob = open(os.path.join(tmp_path, name), "rb").read()
+        assert len(blob) == size and hashlib.sha256(blob).hexdigest() == sha, name
+    r = subprocess.run([EXE] + args, capture_output=True, text=True, timeout=600, env=env)      # a second run loads the files
+    assert r.returncode == 0 and "Both HT files exist" in r.stdout and "Load BIN file" in r.stdout
+    with open(os.path.join(ROOT, "tests", "golden", "small_w1024_ht8_t2_b2_p4.json")) as f:
+        fx = json.load(f)
+    small = tmp_path / "small"
+    small.mkdir()
+    r = subprocess.run([EXE, "-onlygen", "-cpugen", "-dir", str(small), "-t", str(fx["t"]), "-b", str(fx["b"]), "-p", str(fx["p"]), "-w", "10", "-htsz", str(fx["htsz"])],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    gx = "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798"
+    assert open(small / ("%s_%d_%d_htGPUv0.BIN" % (gx, fx["w"], 1 << fx["htsz"])), "rb").read() == bytes.fromhex(fx["htgpu"])
+    assert open(small / ("%d_%d_%d_%d_g2.BIN" % (fx["t"], fx["b"], fx["p"], fx["w"])), "rb").read() == bytes.fromhex(fx["g2"])
+    # files in the reference's format only
+    r = subprocess.run([EXE, "-onlygen", "-cpugen", "-dir", str(small), "-w", "20", "-htsz", "17", "-ext"], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and "-cpugen builds files in the reference`s format" in r.stderr
