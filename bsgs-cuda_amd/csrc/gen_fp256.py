@@ -71,6 +71,87 @@ def column_asm(products, a_name, b_name, first_col, can_carry=True):
     return txt
 
 
+def column_asm_salu(products, a_name, b_name):
+    """One Comba column (>= 3 products, may carry) whose carry-outs are counted by the SCALAR unit: every multiply-add leaves its carry-out as a 64-lane mask in an SGPR
+    pair; the masks are compressed pairwise by a bit-sliced adder on the SALU (p0 = parity plane, k = one weight-2 carry mask per pair: 5 scalar instructions) and the
+    vector unit only adds one mask per PAIR (v_addc with the mask as carry-in) plus one closing step c2 = 2*c2 + p0.  n products: n//2 + 1 vector carry steps instead of n (an odd column
+    starts with a full adder of three masks).  SALU reads of VALU-written SGPRs and VALU carry-ins written by the SALU are interlocked by the hardware (no wait states in the gfx9 hazard table);
+    the scalar instructions of one wave issue beside the vector instructions of the SIMD's other waves."""
+    n = len(products)
+    assert n >= 3
+    a_idx = sorted({i for i, _ in products})
+    b_idx = sorted({j for _, j in products})
+    # operands: 0 acc, 1 c2, 2 mA, 3 mB, 4 p0, 5 k, 6 x, 7 t, then a's, b's
+    opn, k = {}, 8
+    for i in a_idx:
+        opn[("a", i)] = k
+        k += 1
+    for j in b_idx:
+        opn[("b", j)] = k
+        k += 1
+    L = []
+    first_add = [True]
+
+    def mad(m, dst):
+        i, j = products[m]
+        L.append("v_mad_u64_u32 %%0, %%%d, %%%d, %%%d, %%0" % (dst, opn[("a", i)], opn[("b", j)]))
+
+    def addk():
+        L.append("v_addc_co_u32_e64 %%1, vcc, 0, %s, %%5" % ("0" if first_add[0] else "%1"))
+        first_add[0] = False
+
+    m = 0
+    pair = 0
+    if n & 1:
+        # an odd column starts with a TRIPLE: a full adder of three masks (p0 = parity, k = majority), so that no single mask is left over at the end
+        mad(0, 2)
+        mad(1, 3)
+        mad(2, 6)
+        L.append("s_xor_b64 %7, %2, %3")
+        L.append("s_and_b64 %5, %2, %3")
+        L.append("s_xor_b64 %4, %7, %6")
+        L.append("s_and_b64 %7, %7, %6")
+        L.append("s_or_b64 %5, %5, %7")
+        addk()
+        m = 3
+        pair = 1
+    while m + 1 < n:
+        mad(m, 2)
+        mad(m + 1, 3)
+        if pair == 0:
+            L.append("s_xor_b64 %4, %2, %3")
+            L.append("s_and_b64 %5, %2, %3")
+        else:
+            L.append("s_xor_b64 %6, %2, %3")
+            L.append("s_and_b64 %5, %2, %3")
+            L.append("s_and_b64 %7, %4, %6")
+            L.append("s_or_b64 %5, %5, %7")
+            L.append("s_xor_b64 %4, %4, %6")
+        addk()
+        m += 2
+        pair += 1
+    assert m == n
+    L.append("v_addc_co_u32_e64 %1, vcc, %1, %1, %4")
+    ins = ", ".join(['"v"(%s[%d])' % (a_name, i) for i in a_idx] + ['"v"(%s[%d])' % (b_name, j) for j in b_idx])
+    return '    asm("%s"\n        : "+v"(acc), "=&v"(c2), "=&s"(mA), "=&s"(mB), "=&s"(p0), "=&s"(kk), "=&s"(xx), "=&s"(tt)\n        : %s : "vcc", "scc");\n' % ("\\n\\t".join(L), ins)
+
+
+def gen_mul_salu():
+    out = []
+    out.append("// the same product with the carry-outs of every column of three or more products counted on the scalar unit (column_asm_salu)\n")
+    out.append("__device__ __forceinline__ void fe_mul512_s(u32 (&r)[16], const u32 (&a)[8], const u32 (&b)[8])\n{\n")
+    out.append("    u64 acc = 0; u32 c2; u64 cyA, cyB, cyC, mA, mB, p0, kk, xx, tt;\n")
+    for k in range(15):
+        prods = [(i, k - i) for i in range(8) if 0 <= k - i <= 7]
+        if len(prods) >= 3:
+            out.append(column_asm_salu(prods, "a", "b"))
+        else:
+            out.append(column_asm(prods, "a", "b", k == 0, can_carry=k not in (0, 14)))
+        out.append("    r[%d] = (u32)acc; acc = (acc >> 32) | ((u64)c2 << 32);\n" % k)
+    out.append("    r[15] = (u32)acc;\n}\n\n")
+    return "".join(out)
+
+
 def gen_mul():
     out = []
     out.append("// ---- generated by gen_fp256.py: do not edit ----\n")
@@ -137,5 +218,6 @@ def gen_sqr_lo10():
 
 if __name__ == "__main__":
     sys.stdout.write(gen_mul())
+    sys.stdout.write(gen_mul_salu())
     sys.stdout.write(gen_sqr())
     sys.stdout.write(gen_sqr_lo10())

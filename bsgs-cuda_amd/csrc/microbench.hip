@@ -502,7 +502,19 @@ __global__ void __launch_bounds__(256) mulrate_kernel(u32 *out, int iters, u32 s
         for (int i = 0; i < 8; i++) { a.v[i] = seed * 2654435761u + t * 40503u + i; b.v[i] = a.v[i] ^ 0x9E3779B9u; }
         for (int it = 0; it < iters; it++) {
             if (OP == 200) { fe_mul(a, a, b); fe_mul(b, b, a); }
-            else {
+            else if (OP == 207) {                                          // the engine's multiplier with the carries of the product counted on the scalar unit
+                u32 w[16];
+                fe_mul512_s(w, a.v, b.v); fe_reduce512(a, w);
+                fe_mul512_s(w, b.v, a.v); fe_reduce512(b, w);
+            } else if (OP == 206) {
+                u32 w[16];
+                fe_mul512_s(w, a.v, b.v);
+#pragma unroll
+                for (int i = 0; i < 8; i++) a.v[i] = w[i] ^ w[i + 8];
+                fe_mul512_s(w, b.v, a.v);
+#pragma unroll
+                for (int i = 0; i < 8; i++) b.v[i] = w[i] ^ w[i + 8];
+            } else {
                 u32 w[16];
                 fe_mul512(w, a.v, b.v);
 #pragma unroll
@@ -532,6 +544,57 @@ static void sustain_mul(const char *name, double secs, u32 *dout)
         total_ms += ms; n += (double)blocks * threads * iters * 2.0;
     }
     printf("{\"bench\":\"sustain\",\"op\":\"%s\",\"seconds\":%.2f,\"Gmul_per_s\":%.1f}\n", name, total_ms / 1e3, n / (total_ms * 1e-3) / 1e9);
+}
+
+// correctness of fe_mul512_s (carry counts on the scalar unit) against fe_mul512: all 16 words of the 512-bit product, random operands and operands made of
+// 0xFFFFFFFF / 0 / 1 words (every column then carries as often as it can)
+__global__ void salu_check_kernel(const fe *a_in, const fe *b_in, unsigned long long *bad, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const fe a = a_in[t], b = b_in[t];
+    u32 w0[16], w1[16];
+    fe_mul512(w0, a.v, b.v);
+    fe_mul512_s(w1, a.v, b.v);
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) mine += w0[i] != w1[i];
+    if (t & 1) {                                                        // half of the threads of every wave stop here: the masks of inactive lanes must not count
+        if (mine) atomicAdd(bad, mine);
+        return;
+    }
+    fe_mul512(w0, b.v, a.v);
+    fe_mul512_s(w1, b.v, a.v);
+#pragma unroll
+    for (int i = 0; i < 16; i++) mine += w0[i] != w1[i];
+    if (mine) atomicAdd(bad, mine);
+}
+static int salu_check()
+{
+    const int n = 1 << 18;
+    std::vector<fe> a(n), b(n);
+    u64 s = 0x0123456789ABCDEFull;
+    auto rnd = [&]() { s += 0x9E3779B97F4A7C15ull; u64 z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return (u32)((z ^ (z >> 31)) >> 16); };
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 8; k++) {
+            a[i].v[k] = rnd(); b[i].v[k] = rnd();
+            if (i < (1 << 16)) {                                          // words from {0xFFFFFFFF, 0xFFFFFFFE, 0, 1, 0x80000000, random}
+                static const u32 pick[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu, 0u, 1u, 0x80000000u, 0xFFFFFFFFu, 0x7FFFFFFFu};
+                const u32 ra = rnd(), rb = rnd();
+                if ((ra >> 8) & 3) a[i].v[k] = pick[ra & 7];
+                if ((rb >> 8) & 3) b[i].v[k] = pick[rb & 7];
+            }
+        }
+    for (int k = 0; k < 8; k++) { a[0].v[k] = b[0].v[k] = 0xFFFFFFFFu; a[1].v[k] = 0xFFFFFFFFu; b[1].v[k] = 0xFFFFFFFEu; }
+    fe *da, *db; unsigned long long *dbad, h = 0;
+    CK(hipMalloc(&da, n * sizeof(fe))); CK(hipMalloc(&db, n * sizeof(fe))); CK(hipMalloc(&dbad, 8));
+    CK(hipMemcpy(da, a.data(), n * sizeof(fe), hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), n * sizeof(fe), hipMemcpyHostToDevice));
+    CK(hipMemset(dbad, 0, 8));
+    hipLaunchKernelGGL(salu_check_kernel, dim3(n / 256), dim3(256), 0, 0, da, db, dbad, n);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(&h, dbad, 8, hipMemcpyDeviceToHost));
+    printf("{\"bench\":\"salucheck\",\"operand_pairs\":%d,\"mismatching_words\":%llu}\n", n, h);
+    return h ? 1 : 0;
 }
 
 // correctness of the unsaturated multipliers against the engine's fe_mul: chains of dependent products from random and extreme operands, compared canonically
@@ -696,12 +759,15 @@ int main(int argc, char **argv)
     }
     if (argc >= 2 && !strcmp(argv[1], "dpfcheck")) return dpf_check() ? 1 : 0;
     if (argc >= 2 && !strcmp(argv[1], "unsatcheck")) return unsat_check();
+    if (argc >= 2 && !strcmp(argv[1], "salucheck")) return salu_check();
     if (argc >= 4 && !strcmp(argv[1], "power")) {
         u32 *dout; CK(hipMalloc(&dout, 256 * 8 * 256 * 4));
         const int op = atoi(argv[2]); const double secs = atof(argv[3]);
         switch (op) {
         case 200: sustain_mul<200>("fe_mul: integer 256x256 product + fold mod p (the engine's multiplier)", secs, dout); break;
         case 201: sustain_mul<201>("fe_mul512: integer 256x256->512 product only", secs, dout); break;
+        case 206: sustain_mul<206>("fe_mul512_s: the same product, carry-outs counted on the scalar unit (bit-sliced pairs, 43 vector carry steps instead of 62)", secs, dout); break;
+        case 207: sustain_mul<207>("fe_mul512_s + fold mod p", secs, dout); break;
         case 203: sustain_mul<203>("unsat 9x29 (written for the ISA: alignbit carries, multiply-adds for every 64-bit addition): 81 products in 64-bit columns, no carry counts, + fold mod p, normalised in and out", secs, dout); break;
         case 204: sustain_mul<204>("unsat 10x26 (written for the ISA): 100 products in 64-bit columns, no carry counts, + fold mod p, normalised in and out", secs, dout); break;
         case 205: sustain_mul<205>("unsat 9x29 (plain C++: 64-bit shifts and additions as the compiler lowers them)", secs, dout); break;
