@@ -776,6 +776,13 @@ int main(int argc, char **argv)
         case 100: sustain_gups<4>(secs, 16384, dout); break;
         case 101: sustain_gups<8>(secs, 16384, dout); break;
         case 102: sustain_gups<4>(secs, 16, dout); break;          // L2-resident footprint
+        case 110: sustain_gups<4>(secs, 64, dout); break;          // footprints between the L2s (8 x 4 MiB) and HBM: what the 256 MB memory-side cache serves
+        case 111: sustain_gups<4>(secs, 128, dout); break;
+        case 112: sustain_gups<4>(secs, 192, dout); break;
+        case 113: sustain_gups<4>(secs, 256, dout); break;
+        case 114: sustain_gups<4>(secs, 512, dout); break;
+        case 115: sustain_gups<4>(secs, 1024, dout); break;
+        case 116: sustain_gups<4>(secs, 4096, dout); break;
         case 103: sustain_stream(secs, 16384, dout); break;
         case 104: sustain_stream(secs, 16, dout); break;
         case 3: sustain<3>("v_add_u32", 4, secs, dout); break;
