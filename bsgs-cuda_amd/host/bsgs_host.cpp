@@ -24,6 +24,7 @@
 #include <deque>
 #include <memory>
 #include <unistd.h>
+#include <sys/mman.h>
 #include <functional>
 #include <fstream>
 #include <mutex>
@@ -213,7 +214,26 @@ struct HostBuf {
     HostBuf(const HostBuf &) = delete;
     HostBuf &operator=(const HostBuf &) = delete;
     ~HostBuf() { free(p); }
-    void resize(uint64_t bytes) { free(p); p = bytes ? (uint8_t *)malloc(bytes) : nullptr; n = p ? bytes : 0; if (bytes && !p) { fprintf(stderr, "out of host memory (%llu bytes)\n", (unsigned long long)bytes); exit(1); } }
+    // Large images (the 5.4 + 9.6 GB of a -w 30 table) are taken 2 MiB-aligned, offered to transparent huge pages and FIRST-TOUCHED BY SEVERAL THREADS: the kernel
+    // clears every page it hands out, and one thread faulting 15 GB in (inside a device-to-host copy or a read()) is most of a 3.4 s "build + bring to the host" stage
+    void resize(uint64_t bytes)
+    {
+        free(p); p = nullptr; n = 0;
+        if (!bytes) return;
+        const bool big = bytes >= (256ull << 20) && !getenv("BSGS_HOST_NO_PREFAULT");
+        p = big ? (uint8_t *)aligned_alloc(2u << 20, (bytes + (2u << 20) - 1) & ~(uint64_t)((2u << 20) - 1)) : (uint8_t *)malloc(bytes);
+        if (!p) { fprintf(stderr, "out of host memory (%llu bytes)\n", (unsigned long long)bytes); exit(1); }
+        n = bytes;
+        if (!big) return;
+        (void)madvise(p, bytes, MADV_HUGEPAGE);
+        const unsigned nth = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned q = 0; q < nth; q++) th.emplace_back([this, bytes, q, nth]() {
+            const uint64_t lo = bytes / nth * q, hi = q + 1 == nth ? bytes : bytes / nth * (q + 1);
+            for (uint64_t o = lo; o < hi; o += 4096) ((volatile uint8_t *)p)[o] = 0;
+        });
+        for (auto &t : th) t.join();
+    }
     void release() { free(p); p = nullptr; n = 0; }
     uint8_t *data() { return p; }
     const uint8_t *data() const { return p; }
@@ -1067,8 +1087,11 @@ int main(int argc, char **argv)
     // files that were just generated are written by background threads while the start-up goes on (upload, bucket lines, scratch): the buffers they read
     // stay alive until `flush_writers` -- before the staging copies are released, and before any return
     std::vector<std::thread> writers;
+    std::vector<std::function<void()>> pending_writes;               // started once the engines hold their tables: 15 GB going into the page cache next to the upload of the same
+                                                                      // buffers slowed that upload from 0.25 s to 2 s (profiles/r07t_*)
     std::string saved_msg;
-    auto flush_writers = [&]() { for (auto &w : writers) w.join(); writers.clear(); if (!saved_msg.empty()) { fputs(saved_msg.c_str(), stdout); saved_msg.clear(); } };
+    auto start_writers = [&]() { for (auto &f : pending_writes) writers.emplace_back(f); pending_writes.clear(); };
+    auto flush_writers = [&]() { start_writers(); for (auto &w : writers) w.join(); writers.clear(); if (!saved_msg.empty()) { fputs(saved_msg.c_str(), stdout); saved_msg.clear(); } };
     const uint64_t gpu_bytes = 4 * (ht_items + 1) + 4 * c.w, cpu_bytes = 4 * (ht_items + 1) + 8 * c.w, g2_bytes = 64 * S.maxnonce;
     bsgs_dev *d0 = nullptr;
     auto dev0 = [&]() { if (!d0) CK(bsgs_dev_open(gpus[0], &d0)); return d0; };
@@ -1080,8 +1103,8 @@ int main(int argc, char **argv)
         htgpu.resize(gpu_bytes); tables.htcpu.resize(cpu_bytes);
         if (c.cpugen) cpu_build_tables(c.w, c.htsz, htgpu.data(), tables.htcpu.data());
         else CK(bsgs_build_baby_tables(dev0(), c.w, c.htsz, htgpu.data(), tables.htcpu.data(), BSGS_NO_INSTALL));
-        writers.emplace_back([&]() { write_file(f_cpu, tables.htcpu.data(), cpu_bytes); });
-        writers.emplace_back([&]() { write_file(f_gpu, htgpu.data(), gpu_bytes); });
+        pending_writes.emplace_back([&]() { write_file(f_cpu, tables.htcpu.data(), cpu_bytes); });
+        pending_writes.emplace_back([&]() { write_file(f_gpu, htgpu.data(), gpu_bytes); });
         printf("Done in %.1fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
     if (read_file(f_g2, g2, g2_bytes)) printf("Load BIN file:%s\n", f_g2.c_str());
@@ -1095,7 +1118,7 @@ int main(int argc, char **argv)
             CK(bsgs_generate_g2(dev0(), axy, c.t, c.b, c.p));
             CK(bsgs_download_g2(dev0(), g2.data(), g2_bytes));
         }
-        writers.emplace_back([&]() { write_file(f_g2, g2.data(), g2_bytes); });
+        pending_writes.emplace_back([&]() { write_file(f_g2, g2.data(), g2_bytes); });
         saved_msg = "Save BIN file:" + f_g2 + "\n";                  // printed once the file IS on disk (flush_writers)
     }
     if (d0) { bsgs_dev_close(d0); d0 = nullptr; }
@@ -1172,6 +1195,7 @@ int main(int argc, char **argv)
         if (c.ref_quirks) { for (bsgs_dev *d : devs) CK(bsgs_set_flags(d, BSGS_FLAG_REFERENCE_QUIRKS)); printf("Reference-quirk mode: NEGMODP borrow bug reproduced\n"); }
     }
     stage("upload, bucket lines, chain scratch, replicas");
+    start_writers();
     if (!c.joblog.empty()) { S.joblog = fopen(c.joblog.c_str(), "w"); if (!S.joblog) die("Can`t create " + c.joblog); }
     // freshly generated files keep being written BEHIND the search (their writers are joined before the process leaves; a file appears under its name only once it is
     // complete: write_file): the 13 GB of HT files of a -w 30 run cost the first jobs nothing.  Only the resolver's table must be there before the first hit.
