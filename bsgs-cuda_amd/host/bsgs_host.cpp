@@ -25,6 +25,8 @@
 #include <memory>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
 #include <functional>
 #include <fstream>
 #include <mutex>
@@ -96,7 +98,7 @@ struct Config {
     std::string transport = "auto";                // -transport: rccl | peer | auto
     int lanes = -1;                                // -lanes: jobs (public keys of -infile) searched side by side, each on its own engine per GPU; -1 = automatic (2 for short jobs)
     bool w_auto = false;                           // -w auto: the table Tune picks for the range given (tune_plan)
-    bool file_search = false;                      // -sf (hidden in the reference too, 1_9_7File.pb:907-918): htCPU looked up in the file instead of RAM; accepted, the resolver keeps it in RAM
+    bool file_search = false;                      // -sf (hidden in the reference too, 1_9_7File.pb:907-918): htCPU looked up in the file instead of RAM when the file is there at start-up (a table built in this run is still in RAM)
 };
 
 static void die(const std::string &msg)
@@ -240,6 +242,11 @@ struct HostBuf {
     uint64_t size() const { return n; }
     const uint8_t &operator[](uint64_t i) const { return p[i]; }
 };
+static bool file_has_size(const std::string &path, uint64_t expect)
+{
+    struct stat st;
+    return stat(path.c_str(), &st) == 0 && (uint64_t)st.st_size == expect;
+}
 static bool read_file(const std::string &path, HostBuf &out, uint64_t expect)
 {
     std::ifstream f(path, std::ios::binary | std::ios::ate);
@@ -281,6 +288,8 @@ struct MiniBsgs {
 // what every job of a run reads and nobody writes once the start-up is over: the resolver's tables
 struct Tables {
     HostBuf htcpu;
+    int htcpu_fd = -1;                            // -sf 1 (the reference's default, isFilesearch 1_9_7File.pb:178): htCPU stays in its FILE, a lookup is two reads (ReadHTpackFile /
+                                                  // compareHTpackFile 1_9_7File.pb:3056-3099) -- 9.6 GB of host memory and most of the load time of a -w 30 run saved
     MiniBsgs mini;                                // extended tables: the resolver's own small BSGS instead of htCPU
 };
 struct Tile { Scalar key; uint64_t index; };          // counter and dispenser index of a tile: centre = walk_p0 + index * PUBADDBIG
@@ -359,6 +368,21 @@ static size_t get_jobs(Shared &S, size_t n, std::vector<Tile> &out, int slot = -
 }
 
 // ---- resolver: checkerThread 1_9_7File.pb:3933-4296 ---------------------------------------------------------------
+static int htcpu_lookup_file(int fd, uint64_t ht_items, uint64_t key64, uint32_t *pos, int max)
+{
+    const uint32_t b = (uint32_t)key64 & (uint32_t)(ht_items - 1), h = (uint32_t)(key64 >> 32);
+    uint32_t se[2];
+    if (pread(fd, se, 8, (off_t)(4 * (uint64_t)b)) != 8) die("error during loading from file: pos[" + std::to_string(4 * (uint64_t)b) + "] 8b");
+    if (se[1] < se[0] || se[1] - se[0] > (1u << 24)) die("htCPU file: bucket " + std::to_string(b) + " is malformed");
+    const uint32_t cnt = se[1] - se[0];
+    if (!cnt) return 0;
+    std::vector<uint32_t> items(2 * (size_t)cnt);
+    const off_t at = (off_t)(4 * (ht_items + 1) + 8 * (uint64_t)se[0]);
+    if (pread(fd, items.data(), 8 * (size_t)cnt, at) != (ssize_t)(8 * (size_t)cnt)) die("error during loading from file: pos[" + std::to_string((uint64_t)at) + "] " + std::to_string(8 * (uint64_t)cnt) + "b");
+    int n = 0;
+    for (uint32_t k = 0; k < cnt; k++) if (items[2 * k] == h) { if (n < max) pos[n] = items[2 * k + 1]; n++; }
+    return n;
+}
 static int htcpu_lookup(const HostBuf &img, uint64_t ht_items, uint64_t key64, uint32_t *pos, int max)
 {
     const uint32_t b = (uint32_t)key64 & (uint32_t)(ht_items - 1), h = (uint32_t)(key64 >> 32);
@@ -475,7 +499,7 @@ static bool resolve_hit(const Shared &S, const PendingHit &hit, Scalar &key_out)
     if (S.cfg.ext) babies = S.tab->mini.find(T, S.cfg.w);
     else {
         uint32_t pos[64];
-        int np = htcpu_lookup(S.tab->htcpu, 1ull << S.cfg.htsz, T.x.l[0], pos, 64);
+        int np = S.tab->htcpu_fd >= 0 ? htcpu_lookup_file(S.tab->htcpu_fd, 1ull << S.cfg.htsz, T.x.l[0], pos, 64) : htcpu_lookup(S.tab->htcpu, 1ull << S.cfg.htsz, T.x.l[0], pos, 64);
         for (int q = 0; q < std::min(np, 64); q++) babies.push_back((uint64_t)pos[q] + 1);
     }
     for (uint64_t bprime : babies) {
@@ -984,6 +1008,22 @@ static int selftest(int argc, char **argv)
             const TunePlan pl = tune_plan(fr, atof(a[i + 2].c_str()), atoi(a[i + 3].c_str()), 1ull << 24);
             i += 3;
             printf("plan %s | w %.2f htsz %u ext %d build %.3f search %.3f total %.3f\n", plan_flags(pl).c_str(), pl.w_log2, pl.htsz_arg, pl.ext ? 1 : 0, pl.build_s, pl.search_s, pl.total_s);
+        } else if (a[i] == "htlookup" && i + 3 < a.size()) {                 // htCPU file, htsz, then hex 64-bit keys: positions found in RAM and by the two reads of -sf 1
+            const std::string path = a[i + 1];
+            const uint64_t items = 1ull << atoi(a[i + 2].c_str());
+            struct stat st; if (stat(path.c_str(), &st) != 0) return 2;
+            HostBuf img; if (!read_file(path, img, (uint64_t)st.st_size)) return 2;
+            const int fd = open(path.c_str(), O_RDONLY); if (fd < 0) return 2;
+            for (i += 3; i < a.size(); i++) {
+                const uint64_t k = strtoull(a[i].c_str(), nullptr, 16);
+                uint32_t p1[64], p2[64];
+                const int n1 = htcpu_lookup(img, items, k, p1, 64), n2 = htcpu_lookup_file(fd, items, k, p2, 64);
+                std::string o1, o2;
+                for (int q = 0; q < std::min(n1, 64); q++) o1 += " " + std::to_string(p1[q]);
+                for (int q = 0; q < std::min(n2, 64); q++) o2 += " " + std::to_string(p2[q]);
+                printf("htlookup %s ram%s | file%s\n", a[i].c_str(), o1.c_str(), o2.c_str());
+            }
+            close(fd);
         } else if (a[i] == "limits" && i + 2 < a.size()) {                    // w (decimal), htsz: the reference's -w / -htsz limits and UNSAFE question (answer on stdin)
             const std::string m = table_limits(strtoull(a[i + 1].c_str(), nullptr, 10), (uint32_t)atoi(a[i + 2].c_str()), stdin);
             i += 2;
@@ -1096,6 +1136,8 @@ int main(int argc, char **argv)
     bsgs_dev *d0 = nullptr;
     auto dev0 = [&]() { if (!d0) CK(bsgs_dev_open(gpus[0], &d0)); return d0; };
     if (c.ext) printf("Extended table: %llu items, built in GPU memory at start-up (no HT files)\n", (unsigned long long)c.w);
+    else if (c.file_search && file_has_size(f_cpu, cpu_bytes) && read_file(f_gpu, htgpu, gpu_bytes) && (tables.htcpu_fd = open(f_cpu.c_str(), O_RDONLY)) >= 0)
+        printf("Both HT files exist\nhtCPU is searched in its file (%.1f GB not loaded)\n", cpu_bytes / 1e9);
     else if (read_file(f_gpu, htgpu, gpu_bytes) && read_file(f_cpu, tables.htcpu, cpu_bytes)) printf("Both HT files exist\n");
     else {
         printf("Generate HT with %llu items on the %s\n", (unsigned long long)c.w, c.cpugen ? "host CPU" : "GPU");

@@ -52,6 +52,24 @@ def test_key_1e9ad(tmp_path):
     assert "KEY[1]" in out
 
 
+def test_key_1e9ad_files_built_on_the_host_cpu_and_htcpu_searched_in_its_file(tmp_path):
+    """the two host-side modes of the reference around the same search: files made by the CPU-only generator (-onlygen -cpugen: onlygen1_9_6File.pb) are what the
+    engine consumes, and with -sf 1 (the reference's default, 1_9_7File.pb:178) the resolver reads htCPU from its file (two reads per hit) instead of loading it"""
+    geo = ["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14"]
+    out = run(["-onlygen", "-cpugen"] + geo, tmp_path)
+    assert "on the host CPU" in out and "onlygen: files ready" in out
+    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1", "-sf", "1"], tmp_path)
+    assert "Both HT files exist" in out and "htCPU is searched in its file" in out and "Search in file" in out
+    assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
+    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1", "-sf", "0"], tmp_path)                 # in RAM: the same key, a second win.txt entry
+    assert "htCPU is searched in its file" not in out and win_lines(tmp_path)[2] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
+    # -cpugen without -onlygen: the missing files are built on the CPU, then the GPU searches
+    fresh = tmp_path / "fresh"
+    fresh.mkdir()
+    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1", "-cpugen"], fresh)
+    assert "on the host CPU" in out and win_lines(fresh)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
+
+
 @pytest.mark.parametrize("geo", [["-t", "64", "-b", "8", "-p", "16", "-w", "100003", "-htsz", "14"],      # -w above 36: a decimal count (1_9_7File.pb:1009-1022)
                                  ["-t", "96", "-b", "5", "-p", "6", "-w", "77777", "-htsz", "13"],        # 480 engine threads: a ragged last wave
                                  ["-t", "32", "-b", "3", "-p", "10", "-w", "65537", "-htsz", "16"]])      # 96 engine threads, one entry per bucket

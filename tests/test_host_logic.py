@@ -197,3 +197,25 @@ def test_onlygen_on_the_host_cpu_config1_and_small_fixture(tmp_path):
     # files in the reference's format only
     r = subprocess.run([EXE, "-onlygen", "-cpugen", "-dir", str(small), "-w", "20", "-htsz", "17", "-ext"], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode != 0 and "-cpugen builds files in the reference`s format" in r.stderr
+
+
+def test_htcpu_searched_in_its_file_like_the_reference_default(tmp_path):
+    """-sf 1, the reference's default (isFilesearch, 1_9_7File.pb:178): htCPU is not loaded, a lookup is two reads of the file (ReadHTpackFile / compareHTpackFile,
+    1_9_7File.pb:3056-3099).  The file lookup must return what the in-RAM lookup returns -- the position k - 1 of k*G for members, nothing for other keys -- on a table
+    built by -cpugen (w = 2^16 in 2^10 buckets: 64 entries per bucket)."""
+    from pybsgs import ecpy
+    if not os.path.exists(EXE):
+        pytest.skip("host binary not built (run __graft_entry__.build())")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    r = subprocess.run([EXE, "-onlygen", "-cpugen", "-dir", str(tmp_path), "-t", "2", "-b", "2", "-p", "4", "-w", "16", "-htsz", "10"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    f = os.path.join(tmp_path, "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798_65536_1024_htCPUv0.BIN")
+    ks = [1, 2, 3, 1000, 32768, 65535, 65536]
+    keys = [ecpy.mul(k)[0] & (2**64 - 1) for k in ks]
+    outside = [ecpy.mul(k)[0] & (2**64 - 1) for k in (65537, 70000, 2**40 + 7)]
+    out = selftest("htlookup", f, 10, *["%x" % k for k in keys + outside])
+    for k, o in zip(ks, out):
+        ram, fil = o[o.index("ram") + 1:o.index("|")], o[o.index("file") + 1:]
+        assert ram == fil == [str(k - 1)], (k, o)
+    for o in out[len(ks):]:
+        assert o[o.index("ram") + 1:o.index("|")] == o[o.index("file") + 1:] == [], o
