@@ -98,7 +98,7 @@ struct Config {
     std::string transport = "auto";                // -transport: rccl | peer | auto
     int lanes = -1;                                // -lanes: jobs (public keys of -infile) searched side by side, each on its own engine per GPU; -1 = automatic (2 for short jobs)
     bool w_auto = false;                           // -w auto: the table Tune picks for the range given (tune_plan)
-    bool file_search = false;                      // -sf (hidden in the reference too, 1_9_7File.pb:907-918): htCPU looked up in the file instead of RAM when the file is there at start-up (a table built in this run is still in RAM)
+    bool file_search = true;                       // -sf (hidden in the reference too, 1_9_7File.pb:907-918; its default is 1, 1_9_7File.pb:178, and so is this host's): htCPU looked up in the file instead of RAM when the file is there at start-up (a table built in this run is still in RAM)
 };
 
 static void die(const std::string &msg)

@@ -58,11 +58,12 @@ def test_key_1e9ad_files_built_on_the_host_cpu_and_htcpu_searched_in_its_file(tm
     geo = ["-t", "64", "-b", "8", "-p", "16", "-w", "16", "-htsz", "14"]
     out = run(["-onlygen", "-cpugen"] + geo, tmp_path)
     assert "on the host CPU" in out and "onlygen: files ready" in out
-    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1", "-sf", "1"], tmp_path)
-    assert "Both HT files exist" in out and "htCPU is searched in its file" in out and "Search in file" in out
+    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1"], tmp_path)                            # -sf 1 is the default, as in the reference
+    assert "Both HT files exist" in out and "htCPU is searched in its file" in out
     assert win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
-    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1", "-sf", "0"], tmp_path)                 # in RAM: the same key, a second win.txt entry
-    assert "htCPU is searched in its file" not in out and win_lines(tmp_path)[2] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
+    os.remove(os.path.join(tmp_path, "win.txt"))
+    out = run(geo + ["-pb", PUB_1E9AD, "-pk", "1", "-sf", "0"], tmp_path)                 # in RAM: the same key
+    assert "htCPU is searched in its file" not in out and "Search in RAM" in out and win_lines(tmp_path)[0] == "KEY[1]: 0x" + "%064x" % 0x1E9AD
     # -cpugen without -onlygen: the missing files are built on the CPU, then the GPU searches
     fresh = tmp_path / "fresh"
     fresh.mkdir()
