@@ -97,5 +97,9 @@ CompilerEndIf
   bsgs_table_lookup(dev.i, *keys64, n.q, *found)                     ; ... and sampled membership through the shipped probe: n 64-bit keys (low 64 bits of x(k*G)) in, n bytes out
   bsgs_broadcast_tables_ex(*devs, n.l, transport.l, what.l, *transport_used, *seconds)   ; replicas with the transport chosen (0 auto, 1 RCCL over xGMI, 2 peer copies) and reported; what: 1 giants | 2 table
   bsgs_startup_ext_tables(*devs, n.l, w.q, htsz.l, layout.l, strategy.l, transport.l, *report)   ; -w above 32 on several GPUs: 0 = GPU 0 builds + broadcast, 1 = every GPU builds its own (default), 2 = 1/N each + all-gather
+  bsgs_version()                                                     ; -> *ascii: the library's version line (the host's banner)
+  bsgs_table_info(dev.i, *layout, *device_bytes, *overflow_buckets)  ; what is installed: layout code, bytes on the device, over-full buckets (the "Extended table: ..." line)
+  bsgs_set_tiles_per_launch(dev.i, n.l)                              ; short jobs (-infile over a small range): launches of n tiles, scratch sized for them (0 = the engine's default)
+  bsgs_engine_geometry(dev.i, *threads, *giants_per_thread)          ; the engine's own thread x batch factorisation of t*b*p (only the hit index is visible outside)
   bsgs_share_tables(owner.i, twin.i)                                 ; two engines on ONE GPU (two public keys searched side by side): the twin probes the owner's table in place; free the twin first
 EndImport
