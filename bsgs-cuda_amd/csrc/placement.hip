@@ -549,7 +549,8 @@ hipError_t bsgs_lines_malloc(bsgs_dev *d, void **out, size_t bytes)
         // overflow set and the scratch into the same corner.  Measured on one box (profiles/r07n_w35_reserved_group_or_not.log): 3 * 2^30 lines of 64 bytes 28.6 G
         // with a reserved group and 36.7-37.1 G without, 1.5 * 2^30 lines of 128 bytes 34.2-35.2 G against 35.7-35.8 G; and the placement is 1-4 s shorter.
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && (double)bytes > 0.6 * (double)tot) {
+        static const bool anyway = getenv("BSGS_RESERVE_ANYWAY") && atoi(getenv("BSGS_RESERVE_ANYWAY")) != 0;      // A-B only: the reserve also for lines above 0.6 of the HBM
+        if (!anyway && hipMemGetInfo(&fr, &tot) == hipSuccess && (double)bytes > 0.6 * (double)tot) {
             if (getenv("BSGS_BUILD_VERBOSE")) fprintf(stderr, "[place] %.0f GiB of lines cover more than two memory groups of this GPU: no group reserved, one plain allocation\n", bytes / 1073741824.0);
             free_reserve(d);
             return bsgs_big_malloc(out, bytes);
