@@ -557,7 +557,7 @@ static int validate_ext_table(bsgs_dev *d, const u32x4 *lines, int lplog, const 
     if (e != hipSuccess) return fail(BSGS_ERR_HIP, "table validation: %s", hipGetErrorString(e));
     if (h[0] || h[1])
         return fail(BSGS_ERR_ARG, "this lines + overflow-set table breaks the overflow bound (%llu over-full lines hold an entry above their last word, %llu keys of the set are "
-                                  "below their line's last word or belong to no over-full line): a probe would miss entries.  Build it with bsgs_build_baby_table_ext*, or "
+                                  "below their line's last word, missing from its fingerprint or belong to no over-full line): a probe would miss entries.  Build it with bsgs_build_baby_table_ext*, or "
                                   "from an htGPU image whose buckets are sorted ascending", h[0], h[1]);
     return BSGS_OK;
 }

@@ -273,3 +273,67 @@ def test_lanes_two_jobs_side_by_side_keep_list_order_and_recovery(tmp_path):
     assert r.returncode == 0 and "Recovery: listpos 7" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
     win = [l for l in (d / "win.txt").read_bytes().decode().split("\r\n") if l.startswith("KEY[")]
     assert win == ["KEY[%d]: 0x%064x" % (i + 1, k) for i, k in enumerate(keys) if i >= 6]
+
+
+def test_overflow_fingerprint_in_the_headers_of_over_full_lines():
+    """Round 5: the header of an over-full line is 0xFFFF0000 | fingerprint -- bit ((hash >> 16) & 15) set for every hash of the bucket that lives only in the
+    overflow set -- and the probe asks the set only for a hash whose bit is set (giant_kernel.hip.h).  (i) the headers the builder writes are exactly that,
+    recomputed here from the set; (ii) the same table with plain 0xFFFFFFFF headers (no fingerprint: a table built elsewhere) is accepted and gives the same
+    hit lists; (iii) a header that lacks the bit of one of its set-only hashes is refused at install: the probe would never find that key."""
+    import numpy as np
+    import torch
+    import pybsgs
+    from pybsgs import ecpy
+    t, b, p = 64, 2, 16
+    for w, htsz, lay, words in ((1 << 16, 12, pybsgs.TABLE_LINES64_LIST, 16), (1 << 17, 12, pybsgs.TABLE_LINES128_LIST, 32)):     # load 16 / 32: half the lines over-full, by a few entries
+        dev = pybsgs.Device(0)
+        items = 1 << htsz
+        cap = dev.ext_overflow_capacity(w, htsz, lay)
+        lines = torch.empty(items * words, dtype=torch.int32, device="cuda:0")
+        ovf = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+        n_ovf, n_over = dev.build_baby_table_ext_device(w, htsz, lay, lines.data_ptr(), ovf.data_ptr(), cap)
+        dev.install_table_ext_device(lines.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
+        torch.cuda.synchronize()
+        L = lines.cpu().numpy().view(np.uint32).reshape(items, words)
+        S = ovf[:n_ovf].cpu().numpy().view(np.uint64)
+        S = S[S != np.uint64(0xFFFFFFFFFFFFFFFF)]
+        hdr, bound = L[:, 0], L[:, words - 1]
+        over = hdr >= 0xFFFF0000
+        assert int(over.sum()) == n_over and 0.2 * items < n_over < 0.9 * items, n_over
+        assert np.all(hdr[~over] <= words - 1)
+        sb, sh = (S >> np.uint64(32)).astype(np.int64), (S & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        only = over[sb] & (sh != bound[sb])                      # keys the set alone holds (a line's last word is also in the set: the bound)
+        fp = np.zeros(items, dtype=np.uint32)
+        np.bitwise_or.at(fp, sb[only], (np.uint32(1) << ((sh[only] >> np.uint32(16)) & np.uint32(15))).astype(np.uint32))
+        assert np.array_equal(hdr[over], (np.uint32(0xFFFF0000) | fp[over]))
+        sparse = float(np.mean([bin(int(v) & 0xFFFF).count("1") for v in hdr[over]]))
+        assert 1.0 <= sparse <= 8.0, sparse                      # a few set-only hashes per over-full line: a few bits of 16 -- that is what makes the filter bite
+        # (ii) hit lists with the fingerprint == hit lists of the same table without one
+        A = ecpy.addpubg(w)
+        dev.generate_g2(A[0], A[1], t, b, p)
+        ms, cs = _centres(w, t * b * p)
+        # table keys that ONLY the set holds, reached as P - G2[i] / P + G2[i] from crafted centres: k = m -+ (i + 1) * 2w
+        xs_only = {}
+        for k in range(1, 4000):
+            x = ecpy.mul(k)[0]
+            bk, h = x & (items - 1), (x >> 32) & 0xFFFFFFFF
+            if over[bk] and h > bound[bk]:
+                xs_only[k] = (bk, h)
+        assert len(xs_only) > 50
+        ks = sorted(xs_only)[:6]
+        cs = cs + [ecpy.mul((k + (i + 3) * 2 * w) % N) for i, k in enumerate(ks)]        # P + G2[i + 2] = P - (i + 3) * 2w * G = k*G: code 1
+        with_fp = [dev.step(c[0], c[1], 65536) for c in cs]
+        for i, k in enumerate(ks):
+            assert (1, i + 2) in [tuple(h) for h in with_fp[len(cs) - len(ks) + i][0]], (k, i)
+        lines2 = lines.clone()
+        lines2.view(items, words)[torch.from_numpy(over).to("cuda:0"), 0] = -1          # 0xFFFFFFFF: every bit set = always ask the set
+        dev.install_table_ext_device(lines2.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
+        assert [dev.step(c[0], c[1], 65536) for c in cs] == with_fp
+        # (iii) one missing bit
+        bk, h = xs_only[ks[0]]
+        bad = lines.clone()
+        bad[bk * words] = int(np.array([int(hdr[bk]) & ~(1 << ((h >> 16) & 15))], dtype=np.uint32).view(np.int32)[0])
+        torch.cuda.synchronize()
+        with pytest.raises(pybsgs.BsgsError, match="fingerprint"):
+            dev.install_table_ext_device(bad.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
+        dev.close()
