@@ -276,7 +276,7 @@ def test_lanes_two_jobs_side_by_side_keep_list_order_and_recovery(tmp_path):
 
 
 def test_overflow_fingerprint_in_the_headers_of_over_full_lines():
-    """Round 5: the header of an over-full line is 0xFFFF0000 | fingerprint -- bit ((hash >> 16) & 15) set for every hash of the bucket that lives only in the
+    """Round 5: the header of an over-full line is 0x80000000 | fingerprint -- bit min((hash >> 16) & 31, 30) set for every hash of the bucket that lives only in the
     overflow set -- and the probe asks the set only for a hash whose bit is set (giant_kernel.hip.h).  (i) the headers the builder writes are exactly that,
     recomputed here from the set; (ii) the same table with plain 0xFFFFFFFF headers (no fingerprint: a table built elsewhere) is accepted and gives the same
     hit lists; (iii) a header that lacks the bit of one of its set-only hashes is refused at install: the probe would never find that key."""
@@ -298,16 +298,16 @@ def test_overflow_fingerprint_in_the_headers_of_over_full_lines():
         S = ovf[:n_ovf].cpu().numpy().view(np.uint64)
         S = S[S != np.uint64(0xFFFFFFFFFFFFFFFF)]
         hdr, bound = L[:, 0], L[:, words - 1]
-        over = hdr >= 0xFFFF0000
+        over = hdr >= 0x80000000
         assert int(over.sum()) == n_over and 0.2 * items < n_over < 0.9 * items, n_over
         assert np.all(hdr[~over] <= words - 1)
         sb, sh = (S >> np.uint64(32)).astype(np.int64), (S & np.uint64(0xFFFFFFFF)).astype(np.uint32)
         only = over[sb] & (sh != bound[sb])                      # keys the set alone holds (a line's last word is also in the set: the bound)
         fp = np.zeros(items, dtype=np.uint32)
-        np.bitwise_or.at(fp, sb[only], (np.uint32(1) << ((sh[only] >> np.uint32(16)) & np.uint32(15))).astype(np.uint32))
-        assert np.array_equal(hdr[over], (np.uint32(0xFFFF0000) | fp[over]))
-        sparse = float(np.mean([bin(int(v) & 0xFFFF).count("1") for v in hdr[over]]))
-        assert 1.0 <= sparse <= 8.0, sparse                      # a few set-only hashes per over-full line: a few bits of 16 -- that is what makes the filter bite
+        np.bitwise_or.at(fp, sb[only], (np.uint32(1) << np.minimum((sh[only] >> np.uint32(16)) & np.uint32(31), np.uint32(30))).astype(np.uint32))
+        assert np.array_equal(hdr[over], (np.uint32(0x80000000) | fp[over]))
+        sparse = float(np.mean([bin(int(v) & 0x7FFFFFFF).count("1") for v in hdr[over]]))
+        assert 1.0 <= sparse <= 8.0, sparse                      # a few set-only hashes per over-full line: a few bits of 31 -- that is what makes the filter bite
         # (ii) hit lists with the fingerprint == hit lists of the same table without one
         A = ecpy.addpubg(w)
         dev.generate_g2(A[0], A[1], t, b, p)
@@ -332,7 +332,7 @@ def test_overflow_fingerprint_in_the_headers_of_over_full_lines():
         # (iii) one missing bit
         bk, h = xs_only[ks[0]]
         bad = lines.clone()
-        bad[bk * words] = int(np.array([int(hdr[bk]) & ~(1 << ((h >> 16) & 15))], dtype=np.uint32).view(np.int32)[0])
+        bad[bk * words] = int(np.array([int(hdr[bk]) & ~(1 << min((h >> 16) & 31, 30))], dtype=np.uint32).view(np.int32)[0])
         torch.cuda.synchronize()
         with pytest.raises(pybsgs.BsgsError, match="fingerprint"):
             dev.install_table_ext_device(bad.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
