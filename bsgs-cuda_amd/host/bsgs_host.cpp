@@ -788,7 +788,7 @@ static TuneAdvice tune_advice(uint64_t free_bytes)
 // format, brought to the host: the resolver's htCPU and the two HT files), then at most 2^range_bits / (2w * rate * n) seconds are searched -- a small range wants a small
 // table, a large one the largest that fits.  Rates measured on MI355X: reference-format build 8.2 G points/s, extended build 11 G/s (10 G/s into 128-byte
 // lines), tile kernel 40 G giant-steps/s on 64-byte lines (36 G when the whole job is a launch of < 48 tiles), 33 G on 128-byte lines; 25 GB/s to the host.
-struct TunePlan { double w_log2; uint32_t htsz_arg; bool ext; double build_s, search_s, total_s; };
+struct TunePlan { double w_log2; uint32_t htsz_arg; bool ext; double build_s, search_s, total_s; uint64_t w; };      // w = the number of baby points itself (it need not be a power of two)
 static TunePlan tune_plan(uint64_t free_bytes, double range_bits, int n_gpus, uint64_t maxnonce)
 {
     const double budget = (double)free_bytes - std::min(34.0 * 1073741824.0, 0.5 * (double)free_bytes);     // chain scratch (24 GiB at most; the engine sizes its launches by what is left), giants, the builder's own scratch
@@ -797,10 +797,11 @@ static TunePlan tune_plan(uint64_t free_bytes, double range_bits, int n_gpus, ui
     best.total_s = 1e300;
     auto consider = [&](double wl, uint32_t htsz_arg, bool ext, double bytes, double build_rate, double step_rate, double to_host_bytes) {
         if (bytes > budget) return;
-        const double w = std::pow(2.0, wl);
+        const double w = wl > 36.5 ? wl : std::pow(2.0, wl);                                     // (above 36: the count itself, as -w takes it)
+        if (wl > 36.5) wl = std::log2(w);
         const double tiles = std::ceil(range / (4.0 * (double)maxnonce * w)) + 1.0;              // the tile that holds the end of the range is still searched (1_9_7File.pb:2512-2518)
         const double rate = tiles / n < 48.0 ? std::min(step_rate, 36e9) : step_rate;
-        TunePlan p{wl, htsz_arg, ext, w / build_rate + to_host_bytes / 25e9, tiles * 2.0 * (double)maxnonce / rate / n, 0.0};
+        TunePlan p{wl, htsz_arg, ext, w / build_rate + to_host_bytes / 25e9, tiles * 2.0 * (double)maxnonce / rate / n, 0.0, (uint64_t)std::llround(w)};
         p.total_s = p.build_s + p.search_s;
         if (p.total_s < best.total_s * 0.999) best = p;
     };
@@ -810,14 +811,18 @@ static TunePlan tune_plan(uint64_t free_bytes, double range_bits, int n_gpus, ui
     }
     for (int k = 24; k <= 34; k++) consider(k, (uint32_t)(k - 3), true, 64.0 * std::pow(2.0, k - 3) + 0.04 * std::pow(2.0, k), 11e9, k >= 33 ? 39e9 : 40e9, 0.0);      // extended, 64-byte lines, load 8
     consider(35.0, 1610612736u, true, 128.0 * 1610612736.0 + 5.0 * 1073741824.0, 8.5e9, 35.7e9, 0.0);                                                               // 1.5 * 2^30 lines of 128 bytes (load 21.3 of 30)
-    consider(35.0, 3221225472u, true, 64.0 * 3221225472.0 + 17.0 * 1073741824.0, 8.2e9, 36.8e9, 0.0);                                                                // 3 * 2^30 lines of 64 bytes (load 10.67 of 14) + a 16 GiB overflow set: 36.7-37.1 G against 35.7-35.8 G on one box (profiles/r07n_*)
-    if (best.total_s > 1e299) { best = TunePlan{20.0, 18u, false, 0.0, 0.0, 0.0}; }
+    consider(35.0, 3221225472u, true, 64.0 * 3221225472.0 + 17.0 * 1073741824.0, 8.2e9, 38.5e9, 0.0);                                                                // 3 * 2^30 lines of 64 bytes (load 10.67 of 14) + a 16 GiB overflow set: 38.5-38.9 G with the overflow fingerprint in the line headers (r08c, r08d); before it 36.7-37.1 G against 35.7-35.8 G on one box (profiles/r07n_*)
+    // 36 * 2^30 points on the same 3 * 2^30 lines (load 12 of 14; 15.6 % of the lines over-full, a 32 GiB overflow set -- the largest count whose set still has 2^32 slots):
+    // 37.85 G giant-steps/s against 38.5 G at 2^35, each step covering 12.5 % more keys: 2.93e21 keys/s against 2.65e21 (profiles/r08g_more_points_same_lines.log)
+    consider(38654705664.0, 3221225472u, true, 64.0 * 3221225472.0 + 33.0 * 1073741824.0, 6.9e9, 37.8e9, 0.0);
+    if (best.total_s > 1e299) { best = TunePlan{20.0, 18u, false, 0.0, 0.0, 0.0, 1ull << 20}; }
     return best;
 }
 static std::string plan_flags(const TunePlan &p)
 {
     char buf[160];
-    if (p.htsz_arg > 31) snprintf(buf, sizeof buf, "-w %.0f -buckets %u (extended table)", p.w_log2, p.htsz_arg);
+    if (p.htsz_arg > 31 && (p.w & (p.w - 1))) snprintf(buf, sizeof buf, "-w %llu -buckets %u (extended table)", (unsigned long long)p.w, p.htsz_arg);
+    else if (p.htsz_arg > 31) snprintf(buf, sizeof buf, "-w %.0f -buckets %u (extended table)", p.w_log2, p.htsz_arg);
     else snprintf(buf, sizeof buf, "-w %.0f -htsz %u%s", p.w_log2, p.htsz_arg, p.ext ? " -ext" : "");
     return buf;
 }
@@ -1101,7 +1106,7 @@ int main(int argc, char **argv)
         printf("Tune for this range (2^%d keys, %zu GPU engine(s)): %s  -> table %.2fs + search at most %.2fs\n", range_bits, gpus.size(), plan_flags(pl).c_str(), pl.build_s, pl.search_s);
         if (c.w_auto) {
             Config &cw = S.cfg;
-            cw.w = (uint64_t)std::llround(std::pow(2.0, pl.w_log2)); cw.ext = pl.ext; cw.htsz_arg = pl.htsz_arg;
+            cw.w = pl.w; cw.ext = pl.ext; cw.htsz_arg = pl.htsz_arg;
             cw.htsz = pl.htsz_arg <= 31 ? pl.htsz_arg : (uint32_t)std::floor(std::log2((double)pl.htsz_arg));
             printf("-w auto: Items number set to 2^%.2f=%llu, %s\n", pl.w_log2, (unsigned long long)cw.w, pl.ext ? "extended table in GPU memory (no HT files)" : "reference-format HT files");
         }

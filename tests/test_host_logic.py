@@ -108,7 +108,7 @@ def test_tune_advice_for_mi355x():
 def test_tune_plan_for_a_range():
     """Tune for a RANGE (the reference's Tune, 1_9_7File.pb:324-431, knows the GPU only): the table that minimises build + worst-case search.
     A 64-bit range wants a table of 2^30..2^31 points built in GPU memory (no files to bring to the host: 0.3 s all in), an 80-bit range the largest table one
-    GPU holds (-w 35 on 3 * 2^30 bucket lines of 64 bytes), a small GPU stays within its memory, more GPUs shorten the search and never shrink the table."""
+    GPU holds (36 * 2^30 points on 3 * 2^30 bucket lines of 64 bytes), a small GPU stays within its memory, more GPUs shorten the search and never shrink the table."""
     def plan(free, bits, gpus):
         o = selftest("plan", free, bits, gpus)[0]
         f = o[o.index("|") + 1:]
@@ -117,9 +117,13 @@ def test_tune_plan_for_a_range():
     p64 = plan(big, 64, 1)
     assert p64["ext"] and 30 <= p64["w"] <= 31 and p64["total"] < 0.4 and p64["flags"].endswith("-ext")
     p80 = plan(big, 80, 1)
-    assert p80["w"] == 35 and p80["htsz"] == 3221225472 and "-buckets 3221225472" in p80["flags"] and p80["search"] < 600
+    # 36 * 2^30 points on 3 * 2^30 lines of 64 bytes: the count is no power of two, so the flags name it in decimal (as the reference's -w takes counts, 1_9_7File.pb:1009-1022)
+    assert p80["w"] == 35.17 and p80["htsz"] == 3221225472 and "-w 38654705664 -buckets 3221225472" in p80["flags"] and p80["search"] < 600
     p120 = plan(big, 120, 8)
-    assert p120["w"] == 35 and abs(p120["search"] / plan(big, 120, 1)["search"] - 1 / 8) < 1e-3
+    assert p120["w"] == 35.17 and abs(p120["search"] / plan(big, 120, 1)["search"] - 1 / 8) < 1e-3
+    # a GPU with 20 GiB less keeps the 2^35 table on the same lines (its overflow set is 16 GiB instead of 32)
+    p80s = plan(big - 20 * 2**30, 80, 1)
+    assert p80s["w"] == 35 and "-w 35 -buckets 3221225472" in p80s["flags"]
     small = plan(25 * 10**9, 64, 1)
     assert small["w"] <= 30 and 64 * 2 ** small["htsz"] < 25e9
     tiny = plan(8 * 10**9, 80, 1)

@@ -35,13 +35,19 @@ def main():
                 found = int(l.split("0x")[1], 16)
     except OSError:
         pass
+    import re
+    wcount = 2**wlog
+    for l in res.stdout.splitlines():                   # the count the host says it uses ("Items number set to 2^35.17=38654705664"): -w auto may pick one that is no power of two
+        m = re.search(r"Items number set to [^=]*=\s*(\d+)", l)
+        if m:
+            wcount = int(m.group(1))
     job = [l for l in res.stdout.splitlines() if l.startswith("Job time")]
     rec = {"config": "single pubkey, 80-bit range 2^79..2^80-1, -t 256 -b 256 -p 256 %s, 1 GPU" % " ".join(table), "key_fraction_into_range": frac,
            "key": "%x" % key, "found": found == key, "process_wall_s_incl_table_build": dt, "returncode": res.returncode}
     if job:
         f = job[0].split()
         rec.update({"job_time_s": float(f[2].rstrip("s,")), "tiles": int(f[3]), "giant_steps": int(f[3]) * 2**25,
-                    "giant_steps_per_s": int(f[3]) * 2**25 / float(f[2].rstrip("s,")), "keys_covered": int(f[3]) * 4 * 2**24 * 2**wlog})
+                    "giant_steps_per_s": int(f[3]) * 2**25 / float(f[2].rstrip("s,")), "keys_covered": int(f[3]) * 4 * 2**24 * wcount, "baby_points": wcount})
     rec["startup"] = [l for l in res.stdout.splitlines() if l.startswith("[startup]") or l.startswith("Tune for this range") or l.startswith("-w auto")]
     chk = [l for l in res.stdout.splitlines() if l.startswith("Checker:")]
     if chk:
