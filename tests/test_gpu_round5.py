@@ -276,8 +276,9 @@ def test_lanes_two_jobs_side_by_side_keep_list_order_and_recovery(tmp_path):
 
 
 def test_overflow_fingerprint_in_the_headers_of_over_full_lines():
-    """Round 5: the header of an over-full line is 0x80000000 | fingerprint -- bit min((hash >> 16) & 31, 30) set for every hash of the bucket that lives only in the
-    overflow set -- and the probe asks the set only for a hash whose bit is set (giant_kernel.hip.h).  (i) the headers the builder writes are exactly that,
+    """Round 5: the header of an over-full line is 0x80000000 | fingerprint -- bits min((hash >> 16) & 31, 30) and min((hash >> 21) & 31, 30) set for every hash of the bucket
+    that lives only in the overflow set -- and the probe asks the set only for a hash whose bits are set (both of them in the kernels of tables with any number of buckets and
+    in the 128-byte-line kernels, the first one in the kernel of 2^htsz-bucket tables: giant_kernel.hip.h).  (i) the headers the builder writes are exactly that,
     recomputed here from the set; (ii) the same table with plain 0xFFFFFFFF headers (no fingerprint: a table built elsewhere) is accepted and gives the same
     hit lists; (iii) a header that lacks the bit of one of its set-only hashes is refused at install: the probe would never find that key."""
     import numpy as np
@@ -305,9 +306,10 @@ def test_overflow_fingerprint_in_the_headers_of_over_full_lines():
         only = over[sb] & (sh != bound[sb])                      # keys the set alone holds (a line's last word is also in the set: the bound)
         fp = np.zeros(items, dtype=np.uint32)
         np.bitwise_or.at(fp, sb[only], (np.uint32(1) << np.minimum((sh[only] >> np.uint32(16)) & np.uint32(31), np.uint32(30))).astype(np.uint32))
+        np.bitwise_or.at(fp, sb[only], (np.uint32(1) << np.minimum((sh[only] >> np.uint32(21)) & np.uint32(31), np.uint32(30))).astype(np.uint32))
         assert np.array_equal(hdr[over], (np.uint32(0x80000000) | fp[over]))
         sparse = float(np.mean([bin(int(v) & 0x7FFFFFFF).count("1") for v in hdr[over]]))
-        assert 1.0 <= sparse <= 8.0, sparse                      # a few set-only hashes per over-full line: a few bits of 31 -- that is what makes the filter bite
+        assert 1.0 <= sparse <= 14.0, sparse                     # a few set-only hashes per over-full line, two bits each: a few bits of 31 -- that is what makes the filter bite
         # (ii) hit lists with the fingerprint == hit lists of the same table without one
         A = ecpy.addpubg(w)
         dev.generate_g2(A[0], A[1], t, b, p)
@@ -329,11 +331,12 @@ def test_overflow_fingerprint_in_the_headers_of_over_full_lines():
         lines2.view(items, words)[torch.from_numpy(over).to("cuda:0"), 0] = -1          # 0xFFFFFFFF: every bit set = always ask the set
         dev.install_table_ext_device(lines2.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
         assert [dev.step(c[0], c[1], 65536) for c in cs] == with_fp
-        # (iii) one missing bit
+        # (iii) one missing bit: the first of a set-only hash's two, then the second
         bk, h = xs_only[ks[0]]
-        bad = lines.clone()
-        bad[bk * words] = int(np.array([int(hdr[bk]) & ~(1 << min((h >> 16) & 31, 30))], dtype=np.uint32).view(np.int32)[0])
-        torch.cuda.synchronize()
-        with pytest.raises(pybsgs.BsgsError, match="fingerprint"):
-            dev.install_table_ext_device(bad.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
+        for shift in (16, 21):
+            bad = lines.clone()
+            bad[bk * words] = int(np.array([int(hdr[bk]) & ~(1 << min((h >> shift) & 31, 30))], dtype=np.uint32).view(np.int32)[0])
+            torch.cuda.synchronize()
+            with pytest.raises(pybsgs.BsgsError, match="fingerprint"):
+                dev.install_table_ext_device(bad.data_ptr(), ovf.data_ptr(), n_ovf, n_over, w, htsz, lay)
         dev.close()

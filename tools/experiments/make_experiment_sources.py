@@ -39,8 +39,8 @@ def kernel(s):
 ''', '''    u32x4 *chain_piece[BSGS_CHAIN_PIECES_MAX];
     u32 *gate;             // BSGS_SLICE_GATE builds: one progress word per block, [xcd][slot], zeroed before the launch (NULL: no gate)
 ''', where=w)
-    s = edit(s, '''    if (!A.csr) slow &= !m & (xhi >= bound) & (((hdr >> ovf_fingerprint_index(xhi)) & 1u) != 0);
-''', '''    if (!A.csr) slow &= !m & (xhi >= bound) & (((hdr >> ovf_fingerprint_index(xhi)) & 1u) != 0);
+    s = edit(s, '''    if (!A.csr) slow &= !m & (xhi >= bound) & (((hdr >> ovf_fingerprint_index(xhi)) & (BK ? hdr >> ovf_fingerprint_index2(xhi) : 1u) & 1u) != 0);
+''', '''    if (!A.csr) slow &= !m & (xhi >= bound) & (((hdr >> ovf_fingerprint_index(xhi)) & (BK ? hdr >> ovf_fingerprint_index2(xhi) : 1u) & 1u) != 0);
 #ifdef BSGS_NO_OVF_CEILING      /* -D switch, experiments only: never search the overflow set (results WRONG for 0.26 % of the probes): what the remaining slow path costs */
     if (!A.csr) slow = false;
 #endif
