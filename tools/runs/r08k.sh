@@ -9,3 +9,4 @@ cd $R
 ( time python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2>&1 | tail -4 | tee $O/bench_default.time
 ( python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ) | tee $O/smoke.log
 ( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -30 ) | tee $O/pytest_gpu.log
+( python tools/config3_run.py 0.5 /tmp/cfg3 "-w auto" ) 2>&1 | tee $O/config3_80bit_w_auto.json
