@@ -837,6 +837,7 @@ static void tune(int gpu)
     const TuneAdvice a = tune_advice(fr);
     printf("GPU #%d %s: %d CUs, %.0f MB free -> suggested  -t 256 -b 256 -p 256 -w %.2f -htsz %u\n", gpu, name, cus, fr / 1048576.0, a.w_log2, a.htsz);
     if (a.ext) printf("GPU #%d extended table (w above the reference limit): -t 256 -b 256 -p 256 -w %u -htsz %u\n", gpu, a.ext_w_log2, a.ext_htsz);
+    if (a.ext) printf("GPU #%d largest table for long searches (what -w auto takes for a range of 2^80 and more): -t 256 -b 256 -p 256 %s\n", gpu, plan_flags(tune_plan(fr, 120.0, 1, 1ull << 24)).c_str());
     bsgs_dev_close(dev);
 }
 
