@@ -32,6 +32,9 @@ struct KeySink {
     u64 *keys; u32 *pos; u32 pos_base;  // SINK 0: sort key (bucket << 32 | hash) and position of point number idx (197:2561, 2583, 1221)
     u32 *lines; u64 *ovf; u64 ovf_cap; unsigned long long *counters; u32 mask;      // SINK 2 / 3: the line of bucket b counts its arrivals in word 0
     u32 mul;                            // 0: bucket = x & mask ; M: any number of buckets, bucket from 48 bits of the key (giant_kernel.hip.h bucket_mul48)
+    u64 region;                         // SINK 2 / 3: the overflow list is filled in one REGION of this many entries per block of the generator, each with a counter of its own
+                                        // (counters[16 + 16 * block]: 128 bytes apart).  One counter for everybody held the scatter of the large tables 1.5-2.3 s above its
+                                        // random-write bound: 2 * 10^9 appends at 36 * 2^30 points, every one through the same address (profiles/r08s_*)
     u32 b_lo, b_hi;                     // SINK 2 / 3: only buckets [b_lo, b_hi) are filed, in lines[(bucket - b_lo) * WORDS] (a SLICE of the table: one engine of N builds 1/N of the
                                         // lines -- every engine generates every point -- and an all-gather completes them; the whole table: 0, number of buckets)
 };
@@ -49,8 +52,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (SINK == 0 || !pend_line) return;
         if (pend_slot < CAP - 1) pend_line[1 + pend_slot] = pend_hash;             // CAP - 1 arrivals in the line; word CAP is the bound (ext_refine_kernel)
         else {
-            const u64 at = atomicAdd(K.counters + 1, 1ull);
-            if (at < K.ovf_cap) K.ovf[at] = (pend_bucket << 32) | pend_hash;
+            const u64 at = atomicAdd(K.counters + 16 + (u64)blockIdx.x * 16, 1ull);
+            if (at < K.region) K.ovf[(u64)blockIdx.x * K.region + at] = (pend_bucket << 32) | pend_hash;
         }
         pend_line = nullptr;
     };
@@ -322,6 +325,13 @@ extern "C" int bsgs_ext_overflow_capacity(uint64_t w, uint32_t htsz, uint32_t la
     return BSGS_OK;
 }
 
+// the regions of the overflow list (one per block of the generator, KeySink::region) -> one dense array: region b's `count` entries go to out[offset ...)
+static __global__ void __launch_bounds__(256) ovf_compact_kernel(const u64 *__restrict__ list, u64 region, const u64 *__restrict__ count_offset, u64 *__restrict__ out)
+{
+    const u64 b = blockIdx.y, n = count_offset[2 * b], off = count_offset[2 * b + 1];
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) out[off + i] = list[b * region + i];
+}
+
 // the builder proper, for the buckets [b_lo, b_hi) of the table (the whole table: 0, number of buckets): `lines` = the lines of THOSE buckets (b_hi - b_lo lines, device
 // memory), list = room for list_cap overflow entries.  On return the lines are closed and refined and list[0 .. *n_list) holds the overflow entries (bucket << 32 | hash,
 // global bucket numbers), sorted; *overflow_buckets = over-full lines of the slice.  The caller makes the hash set (bsgs_ovf_fill) -- of one list, or of the lists of all slices.
@@ -347,8 +357,12 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
     if (need > fr) return fail(BSGS_ERR_NOMEM, "extended table build needs %.1f GiB of scratch, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
     DevBuf cnt;
     HIPCHK(hipMemsetAsync(lines, 0, nlines * line_bytes, d->stream));
-    HIPCHK(cnt.alloc(16));
-    HIPCHK(hipMemsetAsync(cnt.p, 0, 16, d->stream));
+    uint32_t gen_T = 0, gen_pi = 0;
+    KeyGen::geometry(w, gen_T, gen_pi);
+    const uint64_t gen_blocks = (gen_T + 255) / 256, region = ovf_cap / gen_blocks;       // the generator's blocks (at most 1024) each fill a region of the list
+    const size_t cnt_words = 16 + gen_blocks * 16;                                          // [0] over-full lines (ext_finalize_kernel); [16 + 16 b] entries of block b's region
+    HIPCHK(cnt.alloc(cnt_words * 8));
+    HIPCHK(hipMemsetAsync(cnt.p, 0, cnt_words * 8, d->stream));
     clk.lap(d, "clear the bucket lines");
     {
         KeyGen gen;
@@ -356,6 +370,8 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
         if (rc) return rc;
         KeySink K{};
         K.lines = (u32 *)lines; K.ovf = ovf; K.ovf_cap = ovf_cap; K.counters = cnt.as<unsigned long long>(); K.mask = (u32)(ht_items - 1); K.mul = ext_bucket_mul(htsz);
+        K.region = region;
+        if (gen.T != gen_T) return fail(BSGS_ERR_STATE, "generator geometry changed under the builder");
         K.b_lo = (u32)b_lo; K.b_hi = (u32)std::min<uint64_t>(b_hi, 0xFFFFFFFFull);
         for (uint64_t first = 1; first <= w && rc == BSGS_OK; first += gen.chunk) {
             const uint64_t count = std::min<uint64_t>(gen.chunk, w - first + 1);
@@ -372,21 +388,35 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
     else            hipLaunchKernelGGL(ext_finalize_kernel<3>, dim3(fblocks), dim3(256), 0, d->stream, lines, nlines, cnt.as<unsigned long long>());
     HIPCHK(hipGetLastError());
     unsigned long long h[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(h, cnt.p, 16, hipMemcpyDeviceToHost, d->stream));
+    std::vector<unsigned long long> hc(cnt_words);
+    HIPCHK(hipMemcpyAsync(hc.data(), cnt.p, cnt_words * 8, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
-    if (h[1] > ovf_cap) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries, capacity %llu", h[1], (unsigned long long)ovf_cap);
+    h[0] = hc[0];
+    std::vector<u64> count_offset(2 * gen_blocks);
+    for (uint64_t b = 0; b < gen_blocks; b++) {
+        const unsigned long long nb = hc[16 + 16 * b];
+        // (an entry beyond its region was counted, not written: the table would lack it -- never silently)
+        if (nb > region) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries in the region of generator block %llu, room for %llu (list capacity %llu)", nb, (unsigned long long)b,
+                                     (unsigned long long)region, (unsigned long long)ovf_cap);
+        count_offset[2 * b] = nb; count_offset[2 * b + 1] = h[1];
+        h[1] += nb;
+    }
     clk.lap(d, "close the lines (pad, count)");
     if (h[1]) {
         // OVERFLOW BOUND (giant_kernel.hip.h): sort the overflow list by (bucket, hash), then per bucket keep the smallest hashes in the line
         // and put the smallest of the others into the line's last word
-        DevBuf sorted, tmp;
-        HIPCHK(sorted.alloc(h[1] * 8));
+        // the regions are gathered into one dense array first (`dense`), and the sort writes its output straight back over the list
+        DevBuf dense, tmp, co;
+        HIPCHK(dense.alloc(h[1] * 8));
+        HIPCHK(co.alloc(count_offset.size() * 8));
+        HIPCHK(hipMemcpyAsync(co.p, count_offset.data(), count_offset.size() * 8, hipMemcpyHostToDevice, d->stream));
+        hipLaunchKernelGGL(ovf_compact_kernel, dim3(64, (unsigned)gen_blocks), dim3(256), 0, d->stream, (const u64 *)ovf, (u64)region, co.as<const u64>(), dense.as<u64>());
+        HIPCHK(hipGetLastError());
         size_t tmp_bytes = 0;
         const unsigned key_bits = 32u + (htsz <= 31 ? htsz : 32u);          // (bucket << 32 | hash): the buckets of a non-power-of-two table need all 32 bits
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, key_bits, d->stream));
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, dense.as<u64>(), ovf, (size_t)h[1], 0u, key_bits, d->stream));
         HIPCHK(tmp.alloc(tmp_bytes));
-        HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, ovf, sorted.as<u64>(), (size_t)h[1], 0u, key_bits, d->stream));
-        HIPCHK(hipMemcpyAsync(ovf, sorted.p, h[1] * 8, hipMemcpyDeviceToDevice, d->stream));
+        HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dense.as<u64>(), ovf, (size_t)h[1], 0u, key_bits, d->stream));
         const int rblocks = (int)std::min<uint64_t>((h[1] + 255) / 256, 1u << 16);
         if (lplog == 2) hipLaunchKernelGGL(ext_refine_kernel<2>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1], (u64)b_lo);
         else            hipLaunchKernelGGL(ext_refine_kernel<3>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1], (u64)b_lo);

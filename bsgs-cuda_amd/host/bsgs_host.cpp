@@ -811,10 +811,12 @@ static TunePlan tune_plan(uint64_t free_bytes, double range_bits, int n_gpus, ui
     }
     for (int k = 24; k <= 34; k++) consider(k, (uint32_t)(k - 3), true, 64.0 * std::pow(2.0, k - 3) + 0.04 * std::pow(2.0, k), 11e9, k >= 33 ? 39e9 : 40e9, 0.0);      // extended, 64-byte lines, load 8
     consider(35.0, 1610612736u, true, 128.0 * 1610612736.0 + 5.0 * 1073741824.0, 8.5e9, 35.7e9, 0.0);                                                               // 1.5 * 2^30 lines of 128 bytes (load 21.3 of 30)
-    consider(35.0, 3221225472u, true, 64.0 * 3221225472.0 + 17.0 * 1073741824.0, 8.2e9, 38.5e9, 0.0);                                                                // 3 * 2^30 lines of 64 bytes (load 10.67 of 14) + a 16 GiB overflow set: 38.5-38.9 G with the overflow fingerprint in the line headers (r08c, r08d); before it 36.7-37.1 G against 35.7-35.8 G on one box (profiles/r07n_*)
+    consider(35.0, 3221225472u, true, 64.0 * 3221225472.0 + 17.0 * 1073741824.0, 5.5e9, 38.5e9, 0.0);                                                                // 3 * 2^30 lines of 64 bytes (load 10.67 of 14) + a 16 GiB overflow set: 38.5-38.9 G with the overflow fingerprint in the line headers (r08c, r08d); before it 36.7-37.1 G against 35.7-35.8 G on one box (profiles/r07n_*)
     // 36 * 2^30 points on the same 3 * 2^30 lines (load 12 of 14; 15.6 % of the lines over-full, a 32 GiB overflow set -- the largest count whose set still has 2^32 slots):
     // 37.85 G giant-steps/s against 38.5 G at 2^35, each step covering 12.5 % more keys: 2.93e21 keys/s against 2.65e21 (profiles/r08g_more_points_same_lines.log)
-    consider(38654705664.0, 3221225472u, true, 64.0 * 3221225472.0 + 33.0 * 1073741824.0, 6.9e9, 37.8e9, 0.0);
+    // (build rates of the two large tables: the WALL the host spends -- 8.0 s for 36 * 2^30 points, of which 3.0 s are the builder's kernels, 2.5-3.9 s one hipMalloc of 192 GiB
+    // on a driver that clears what it hands out, the rest the overflow set and the validation: profiles/r08t_config3_key_near_the_start.json, r08t_builder_stages.log)
+    consider(38654705664.0, 3221225472u, true, 64.0 * 3221225472.0 + 33.0 * 1073741824.0, 4.8e9, 37.8e9, 0.0);
     if (best.total_s > 1e299) { best = TunePlan{20.0, 18u, false, 0.0, 0.0, 0.0, 1ull << 20}; }
     return best;
 }
