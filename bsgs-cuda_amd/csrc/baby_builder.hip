@@ -335,8 +335,10 @@ static __global__ void __launch_bounds__(256) ovf_compact_kernel(const u64 *__re
 // the builder proper, for the buckets [b_lo, b_hi) of the table (the whole table: 0, number of buckets): `lines` = the lines of THOSE buckets (b_hi - b_lo lines, device
 // memory), list = room for list_cap overflow entries.  On return the lines are closed and refined and list[0 .. *n_list) holds the overflow entries (bucket << 32 | hash,
 // global bucket numbers), sorted; *overflow_buckets = over-full lines of the slice.  The caller makes the hash set (bsgs_ovf_fill) -- of one list, or of the lists of all slices.
+// scratch / scratch_bytes: device memory the caller lends for the sort of the overflow list (the whole-table build lends the buffer of the overflow SET, which is filled only
+// afterwards: 30 GiB less to ask the driver for at 36 * 2^30 points, and it clears what it hands out); nullptr = allocate.
 static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32x4 *lines, uint64_t b_lo, uint64_t b_hi, u64 *list, uint64_t list_cap, uint64_t *n_list,
-                           uint64_t *overflow_buckets)
+                           uint64_t *overflow_buckets, void *scratch = nullptr, size_t scratch_bytes = 0)
 {
     u64 *ovf = list;
     const uint64_t ovf_cap = list_cap;
@@ -406,17 +408,24 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
         // OVERFLOW BOUND (giant_kernel.hip.h): sort the overflow list by (bucket, hash), then per bucket keep the smallest hashes in the line
         // and put the smallest of the others into the line's last word
         // the regions are gathered into one dense array first (`dense`), and the sort writes its output straight back over the list
-        DevBuf dense, tmp, co;
-        HIPCHK(dense.alloc(h[1] * 8));
-        HIPCHK(co.alloc(count_offset.size() * 8));
-        HIPCHK(hipMemcpyAsync(co.p, count_offset.data(), count_offset.size() * 8, hipMemcpyHostToDevice, d->stream));
-        hipLaunchKernelGGL(ovf_compact_kernel, dim3(64, (unsigned)gen_blocks), dim3(256), 0, d->stream, (const u64 *)ovf, (u64)region, co.as<const u64>(), dense.as<u64>());
-        HIPCHK(hipGetLastError());
+        DevBuf dense_own, tmp_own, co;
+        const size_t dense_bytes = ((size_t)h[1] * 8 + 255) & ~(size_t)255;
         size_t tmp_bytes = 0;
         const unsigned key_bits = 32u + (htsz <= 31 ? htsz : 32u);          // (bucket << 32 | hash): the buckets of a non-power-of-two table need all 32 bits
-        HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, dense.as<u64>(), ovf, (size_t)h[1], 0u, key_bits, d->stream));
-        HIPCHK(tmp.alloc(tmp_bytes));
-        HIPCHK(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dense.as<u64>(), ovf, (size_t)h[1], 0u, key_bits, d->stream));
+        HIPCHK(rocprim::radix_sort_keys(nullptr, tmp_bytes, (u64 *)nullptr, ovf, (size_t)h[1], 0u, key_bits, d->stream));
+        u64 *dense = nullptr;
+        void *tmp = nullptr;
+        if (scratch && dense_bytes + tmp_bytes <= scratch_bytes) { dense = (u64 *)scratch; tmp = (char *)scratch + dense_bytes; }
+        else {
+            HIPCHK(dense_own.alloc(dense_bytes));
+            HIPCHK(tmp_own.alloc(tmp_bytes));
+            dense = dense_own.as<u64>(); tmp = tmp_own.p;
+        }
+        HIPCHK(co.alloc(count_offset.size() * 8));
+        HIPCHK(hipMemcpyAsync(co.p, count_offset.data(), count_offset.size() * 8, hipMemcpyHostToDevice, d->stream));
+        hipLaunchKernelGGL(ovf_compact_kernel, dim3(64, (unsigned)gen_blocks), dim3(256), 0, d->stream, (const u64 *)ovf, (u64)region, co.as<const u64>(), dense);
+        HIPCHK(hipGetLastError());
+        HIPCHK(rocprim::radix_sort_keys(tmp, tmp_bytes, dense, ovf, (size_t)h[1], 0u, key_bits, d->stream));
         const int rblocks = (int)std::min<uint64_t>((h[1] + 255) / 256, 1u << 16);
         if (lplog == 2) hipLaunchKernelGGL(ext_refine_kernel<2>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1], (u64)b_lo);
         else            hipLaunchKernelGGL(ext_refine_kernel<3>, dim3(rblocks), dim3(256), 0, d->stream, (u32 *)lines, ovf, (u64)h[1], (u64)b_lo);
@@ -435,7 +444,7 @@ static int ext_build_into(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u32
     DevBuf listb;
     HIPCHK(listb.alloc(ovf_cap * 8));
     uint64_t n_list = 0;
-    int rc = ext_build_lines(d, w, htsz, lplog, lines, 0, ext_buckets(htsz), listb.as<u64>(), ovf_cap, &n_list, overflow_buckets);
+    int rc = ext_build_lines(d, w, htsz, lplog, lines, 0, ext_buckets(htsz), listb.as<u64>(), ovf_cap, &n_list, overflow_buckets, ovf_table, (size_t)ovf_slots * 8);
     if (rc) return rc;
     rc = bsgs_ovf_fill(d, listb.as<u64>(), n_list, ovf_table, ovf_slots);
     if (rc) return rc;
