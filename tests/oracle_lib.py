@@ -105,6 +105,10 @@ def lib():
             "o_fast_tile_slice_keys_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, u8p]),
             "o_fast_keys_of_scalars_mt": (C.c_int, [u8p, C.c_uint64, u8p, C.c_int]),
             "o_tile_xs": (C.c_int, [ppt, ppt, C.c_uint32, pfe, pfe, pfe]),
+            "o_bucket_ext": (C.c_uint32, [C.c_uint64, C.c_uint64]),
+            "o_ext_probe": (C.c_int, [u8p, C.c_uint64, C.c_uint64, C.c_uint64]),
+            "o_tile_ref_ext": (C.c_uint64, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint64, C.c_uint64, C.c_uint32,
+                                            C.c_uint64, C.c_uint64, C.c_int, C.POINTER(Hit), C.c_uint64]),
             "o_job_init": (C.c_int, [C.POINTER(Job), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64,
                                      C.c_uint32, pfe, ppt, pfe]),
             "o_getjob": (None, [C.POINTER(Job), pfe, ppt]),
@@ -225,6 +229,25 @@ def tile_slice_keys(P, g2buf, t, b, p, tid0, tid1, flags=0):
     ptr = g2buf.ctypes.data_as(C.c_void_p) if hasattr(g2buf, "ctypes") else C.cast(g2buf, C.c_void_p)
     lib().o_tile_ref_slice_keys(C.byref(Pt.from_ints(*P)), ptr, t, b, p, flags, tid0, tid1, keys.ctypes.data_as(C.c_void_p))
     return keys
+
+
+def tile_ref_ext(P, g2, t, b, p, ck, buckets, flags=0, tid0=0, tid1=None, phase0=True, max_hits=65536):
+    """the tile model over a table with ANY number of buckets, given as its ascending composite keys (bucket << 32 | hash), numpy uint64:
+    (sorted hits [(code, idx)], total).  Whole tile incl. the probe of P itself by default; a thread slice with tid0 / tid1 / phase0=False."""
+    import numpy as np
+    ck = np.ascontiguousarray(ck, dtype=np.uint64)
+    hits = (Hit * max_hits)()
+    g2b = C.create_string_buffer(g2, len(g2)) if isinstance(g2, bytes) else g2
+    ptr = g2b.ctypes.data_as(C.c_void_p) if hasattr(g2b, "ctypes") else C.cast(g2b, C.c_void_p)
+    n = lib().o_tile_ref_ext(C.byref(Pt.from_ints(*P)), ptr, t, b, p, ck.ctypes.data_as(C.c_void_p), len(ck), buckets, flags,
+                             tid0, t * b if tid1 is None else tid1, 1 if phase0 else 0, hits, max_hits)
+    return [(hits[i].code, hits[i].idx) for i in range(min(n, max_hits))], n
+
+
+def ext_probe(ck, buckets, key64):
+    import numpy as np
+    ck = np.ascontiguousarray(ck, dtype=np.uint64)
+    return lib().o_ext_probe(ck.ctypes.data_as(C.c_void_p), len(ck), buckets, key64)
 
 
 def fast_tile_slice_keys(P, g2buf, t, b, p, tid0, tid1, nthreads=1):
