@@ -2,6 +2,7 @@
 #pragma once
 #include "giant_kernel.hip.h"
 #include "../../include/bsgs_hip.h"
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,8 @@ struct bsgs_dev {
     bool lines_owned = true;    // false: lines / ovf were handed over by bsgs_install_table_ext_device (borrowed)
     u64 *ovf = nullptr;         // "lines + overflow list" formats (no CSR on the device): hash set of (bucket << 32 | hash)
     uint64_t ovf_n = 0;         // slots (power of two)
+    bool bound_copies = true;   // the set holds a COPY of every over-full (and exactly full) line's last word: the direct builder's convention, assumed for tables installed from outside;
+                                // false: made from an htGPU image (the line holds real entries only).  Only the census' duplicate count depends on it.
     uint64_t ht_items = 0, w = 0, lines_bytes = 0, overflow = 0;
     uint32_t bucket_mul = 0;    // 0: ht_items is a power of two, bucket = x & (ht_items - 1); else = ht_items: any number of buckets, bucket from 48 bits of the key (giant_kernel.hip.h bucket_mul48; extended tables, 128-byte lines)
     uint32_t layout = 0;        // probe layout: 1 csr, 2 lines64, 3 lines128 (ovf != NULL: reported as 4 / 5)
@@ -115,8 +118,15 @@ template <typename T> static inline hipError_t bsgs_big_malloc(T **p, size_t byt
 hipError_t bsgs_launch_tile_lines64(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
 hipError_t bsgs_launch_tile_lines128(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
 hipError_t bsgs_launch_tile_lines64_any(const TileArgs &A, dim3 grid, dim3 block, size_t lds, hipStream_t st, uint32_t group, bool dbg, const char **name);
+// bsgs_hip.hip (the engine core)
 void bsgs_free_table(bsgs_dev *d);
 void bsgs_free_recv(bsgs_dev *d);                            // receive buffers that were never installed
+int bsgs_set_geometry(bsgs_dev *d, uint32_t t, uint32_t b, uint32_t p);      // (re)allocates the giants for this geometry and picks the engine's own batching
+uint32_t bsgs_chain_group(const bsgs_dev *d, uint32_t pi);   // giants per stored running product of the tile kernel a launch with batch length pi takes (4 / 2 chained, 1 per-giant)
+uint32_t bsgs_auto_tiles_per_launch(const bsgs_dev *d);      // the launch size in effect
+static inline bool bsgs_lines_layout(const bsgs_dev *d) { return d->layout == BSGS_TABLE_LINES64 || d->layout == BSGS_TABLE_LINES128; }
+static inline size_t bsgs_hitbuf_bytes(const bsgs_dev *d) { return 64 + (size_t)d->max_hits * 16; }
+static inline void bsgs_le_to_fe(fe &f, const uint8_t *le) { memcpy(f.v, le, 32); }
 uint64_t bsgs_ovf_slots(uint64_t entries);                   // size of the overflow hash set for `entries` keys (power of two, load <= 1/2)
 int bsgs_ovf_fill(bsgs_dev *d, const u64 *list, uint64_t n, u64 *table, uint64_t slots);   // table := hash set of list[0..n)
 // hand a finished "lines + overflow list" table to the engine (it becomes the owner of both buffers)

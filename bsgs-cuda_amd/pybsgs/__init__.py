@@ -24,10 +24,13 @@ NATIVE_SYMBOLS = [
     "bsgs_enqueue", "bsgs_collect", "bsgs_dev_stream", "bsgs_steps_per_tile", "bsgs_selftest_fe", "bsgs_selftest_xs",
     "bsgs_bench_random_read", "bsgs_bench_stream", "bsgs_bench_modmul", "bsgs_set_tiles_per_launch", "bsgs_launch_count", "bsgs_build_baby_tables", "bsgs_build_baby_tables_device", "bsgs_build_baby_table_ext", "bsgs_ext_overflow_capacity", "bsgs_build_baby_table_ext_device", "bsgs_install_table_ext_device", "bsgs_profile_phases",
     "bsgs_set_walk", "bsgs_enqueue_walk", "bsgs_run_walk", "bsgs_walk_centres", "bsgs_set_flags", "bsgs_quirk_count", "bsgs_broadcast_tables",
-    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_debug_realloc", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_chain_grades", "bsgs_debug_grade_rule", "bsgs_debug_xcd_profile",
-    "bsgs_table_checksum", "bsgs_debug_corrupt_table", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
+    "bsgs_tiles_per_launch", "bsgs_engine_geometry", "bsgs_run_digest", "bsgs_selftest_lo64", "bsgs_compat_stats", "bsgs_debug_buffers", "bsgs_alloc_stats", "bsgs_tune_placement", "bsgs_chain_placement", "bsgs_chain_grades", "bsgs_debug_grade_rule", "bsgs_debug_xcd_profile",
+    "bsgs_table_checksum", "bsgs_sample_g2", "bsgs_alloc_table_ext_recv", "bsgs_debug_last_kernel", "bsgs_compat_stats_ex", "bsgs_debug_table_owner", "bsgs_prepare", "bsgs_debug_last_batching", "bsgs_debug_narrow_batching",
     "bsgs_table_census", "bsgs_table_lookup", "bsgs_broadcast_tables_ex", "bsgs_startup_ext_tables", "bsgs_build_baby_table_ext_slice", "bsgs_build_overflow_set", "bsgs_debug_fabric_selftest", "bsgs_share_tables",
 ]
+# exported by the TEST build only (build/libbsgs_hip_test.so = the shipped objects + csrc/test_hooks.hip; include/bsgs_hip.h under BSGS_TEST_HOOKS)
+TEST_HOOK_SYMBOLS = ["bsgs_debug_corrupt_table", "bsgs_debug_realloc"]
+TEST_LIB_PATH = os.path.join(PKG_ROOT, "build", "libbsgs_hip_test.so")
 COMPAT_SYMBOLS = [
     "cuInit", "cuDeviceGetCount", "cuDeviceGet", "cuDeviceGetName", "cuDeviceTotalMem_v2", "cuDeviceComputeCapability",
     "cuDeviceGetAttribute", "cuCtxCreate_v2", "cuCtxDestroy_v2", "cuCtxSynchronize", "cuMemGetInfo_v2", "cuModuleLoadData",
@@ -130,6 +133,7 @@ def lib():
             "bsgs_build_overflow_set": [vp, vp, C.c_uint64, vp, C.c_uint64],
             "bsgs_debug_fabric_selftest": [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)],
             "bsgs_table_lookup": [vp, vp, C.c_uint64, vp],
+            "bsgs_sample_g2": [vp, vp, C.c_uint32, vp],
             "bsgs_debug_corrupt_table": [vp, C.c_uint64, C.c_uint32],
             "bsgs_debug_table_owner": [vp, C.POINTER(C.c_int)],
             "bsgs_prepare": [vp],
@@ -360,9 +364,28 @@ class Device:
         _chk(self.L.bsgs_table_lookup(self.h, C.c_void_p(addr), n, C.cast(out, C.c_void_p)))
         return [bool(x) for x in out]
 
+    def _test_hook(self, name):
+        fn = getattr(self.L, name, None)
+        if fn is None:
+            raise BsgsError("%s is a TEST hook: it lives in %s only (set BSGS_LIB_PATH to it before pybsgs loads its library); the shipped library does not export it" % (name, TEST_LIB_PATH))
+        return fn
+
     def debug_corrupt_table(self, byte_offset, xor_mask=1):
-        """test hook: flip bits of one byte of the installed table (what replica verification must catch)"""
-        _chk(self.L.bsgs_debug_corrupt_table(self.h, byte_offset, xor_mask))
+        """TEST BUILD hook: flip bits of one byte of the installed table (what the verification must catch)"""
+        _chk(self._test_hook("bsgs_debug_corrupt_table")(self.h, byte_offset, xor_mask))
+
+    def sample_g2(self, indices):
+        """giants by number as (x, y) integer pairs (what a host compares with (i + 1) * ADDPUBG before it searches: checkGiantArr 1_9_7File.pb:1524-1559)"""
+        import array
+        a = array.array("Q", indices)
+        n = len(a)
+        if not n:
+            return []
+        out = C.create_string_buffer(64 * n)
+        addr, _ = a.buffer_info()
+        _chk(self.L.bsgs_sample_g2(self.h, C.c_void_p(addr), n, C.cast(out, C.c_void_p)))
+        raw = out.raw
+        return [(int.from_bytes(raw[64 * i:64 * i + 32], "little"), int.from_bytes(raw[64 * i + 32:64 * i + 64], "little")) for i in range(n)]
 
     def table_owned(self):
         v = C.c_int()
@@ -557,7 +580,7 @@ class Device:
                 "kept": (int(chosen[0]), int(chosen[1])), "final_ms": round(fin.value, 2)}
 
     def debug_realloc(self, which, spacer_bytes=0):
-        _chk(self.L.bsgs_debug_realloc(self.h, which, spacer_bytes))
+        _chk(self._test_hook("bsgs_debug_realloc")(self.h, which, spacer_bytes))
 
     def bench_modmul(self):
         g = C.c_double()

@@ -31,3 +31,20 @@ def free_hbm(want_bytes, wait_s=20.0):
         if free >= want_bytes or time.time() - t0 > wait_s:
             return free
         time.sleep(0.5)
+
+
+def rerun_in_test_library(request, timeout=1800):
+    """Tests of the VERIFICATION need a corrupted table, and the hook that corrupts one (bsgs_debug_corrupt_table) lives in build/libbsgs_hip_test.so only
+    -- the shipped objects plus csrc/test_hooks.hip -- never in the library the other tests (and the driver) load.  Such a test starts with
+        if rerun_in_test_library(request): return
+    which runs this very test in a child pytest whose pybsgs loads the test library (BSGS_LIB_PATH) and asserts that it passed there; inside the child it returns
+    False and the body runs."""
+    import subprocess
+    import pybsgs
+    if os.environ.get("BSGS_LIB_PATH") == pybsgs.TEST_LIB_PATH:
+        return False
+    assert os.path.exists(pybsgs.TEST_LIB_PATH), "make -C bsgs-cuda_amd builds build/libbsgs_hip_test.so"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", request.node.nodeid], cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, BSGS_LIB_PATH=pybsgs.TEST_LIB_PATH))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    return True

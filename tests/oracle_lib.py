@@ -104,6 +104,10 @@ def lib():
                                                C.POINTER(C.c_uint64)]),
             "o_fast_tile_slice_keys_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, u8p]),
             "o_fast_keys_of_scalars_mt": (C.c_int, [u8p, C.c_uint64, u8p, C.c_int]),
+            "o_bench_port_mt": (C.c_int, [ppt, u8p, C.c_uint32, C.c_uint32, C.c_uint32, u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+            "o_bench_fast_mt": (C.c_int, [ppt, u8p, C.c_uint64, C.c_uint32, u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
             "o_tile_xs": (C.c_int, [ppt, ppt, C.c_uint32, pfe, pfe, pfe]),
             "o_bucket_ext": (C.c_uint32, [C.c_uint64, C.c_uint64]),
             "o_ext_probe": (C.c_int, [u8p, C.c_uint64, C.c_uint64, C.c_uint64]),

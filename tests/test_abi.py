@@ -19,9 +19,15 @@ def libpath():
     return pybsgs.LIB_PATH
 
 
-def declared_symbols():
+def declared_symbols(test_hooks=False):
+    """the names include/bsgs_hip.h declares: outside its `#ifdef BSGS_TEST_HOOKS` block (the shipped ABI), or inside it (the test build's additions)"""
     txt = open(HDR).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    hooks = "".join(re.findall(r"#ifdef BSGS_TEST_HOOKS\n(.*?)#endif", txt, flags=re.S))
+    if test_hooks:
+        txt = hooks
+    else:
+        txt = re.sub(r"#ifdef BSGS_TEST_HOOKS\n.*?#endif", "", txt, flags=re.S)
     names = re.findall(r"\b(?:int|const char \*)\s*\*?\s*((?:bsgs_|cu)[A-Za-z0-9_]+)\s*\(", txt)
     return sorted(set(names))
 
@@ -35,6 +41,27 @@ def test_library_exports_every_declared_symbol(libpath):
     L = ctypes.CDLL(libpath)
     missing = [s for s in declared_symbols() if not hasattr(L, s)]
     assert not missing, missing
+
+
+def test_test_hooks_live_in_the_test_library_only(libpath):
+    """bsgs_debug_corrupt_table / bsgs_debug_realloc are not part of the shipped ABI; build/libbsgs_hip_test.so (the same objects +
+    csrc/test_hooks.hip) carries them for the verification tests, and the shipped host has no BSGS_TEST_CORRUPT_ENGINE hook compiled in"""
+    import pybsgs
+    hooks = declared_symbols(test_hooks=True)
+    assert hooks == sorted(pybsgs.TEST_HOOK_SYMBOLS) and hooks
+    out = subprocess.run(["nm", "-D", "--defined-only", libpath], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert not (set(hooks) & exported), set(hooks) & exported
+    assert not [s for s in exported if "corrupt" in s or "realloc" in s]
+    test_lib = pybsgs.TEST_LIB_PATH
+    assert os.path.exists(test_lib)
+    out = subprocess.run(["nm", "-D", "--defined-only", test_lib], capture_output=True, text=True).stdout
+    exported_t = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert set(hooks) <= exported_t and exported <= exported_t
+    build = os.path.dirname(libpath)
+    ship, test = open(os.path.join(build, "bsgs_mi355x"), "rb").read(), open(os.path.join(build, "bsgs_mi355x_test"), "rb").read()
+    assert b"BSGS_TEST_CORRUPT_ENGINE" not in ship and b"BSGS_TEST_CORRUPT_ENGINE" in test
+    assert b"libbsgs_hip_test" not in ship
 
 
 def test_no_silent_cpu_fallback(libpath):

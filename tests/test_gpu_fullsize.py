@@ -106,7 +106,7 @@ def verify_table(dev, w, n_in=100000, n_out=100000, seed=1, extra_k=()):
 def test_census_and_sampled_membership_of_small_tables_in_every_layout():
     """census + membership (verify_table) on small tables in every device layout: the three made from a reference-format image (with and without resident
     CSR), the CSR image alone, direct-built 64- and 128-byte lines with heavy overflow, and direct-built tables with a bucket count that is NOT a power
-    of two (the bucket then comes from 48 bits of the key; 64- and 128-byte lines); then a corrupted line header must show in the census."""
+    of two (the bucket then comes from 48 bits of the key; 64- and 128-byte lines)."""
     import pybsgs
     dev = pybsgs.Device(0)
     wexp, htsz = 20, 17                                    # load 8
@@ -133,11 +133,24 @@ def test_census_and_sampled_membership_of_small_tables_in_every_layout():
         c, _, fp = verify_table(dev, w2, 20000, 20000, seed=hb)
         assert c["overfull_lines"] == over and c["unsorted_lines"] == 0, (c, over)      # (round 5: the direct builder closes its lines sorted)
         assert fp <= 3
-    # a damaged table is seen: one bit of a line header (entry count 8 -> 9: a word of padding becomes an "entry")
-    c0 = dev.table_census()
-    dev.debug_corrupt_table(128 * 7, 1)
-    c1 = dev.table_census()
-    assert c1["total"] != c0["total"] or c1["malformed_lines"] > 0, (c0, c1)
+    dev.close()
+
+
+def test_census_sees_a_damaged_line_header(request):
+    """one bit of a line header (an entry count changes by one: a word of padding becomes an "entry", or an entry is dropped) shows in the census
+    (runs in the TEST library: the hook that damages a table is not part of the shipped one)"""
+    from conftest import rerun_in_test_library
+    if rerun_in_test_library(request):
+        return
+    import pybsgs
+    dev = pybsgs.Device(0)
+    for w2, hb, layout, words in ((1000003, 48611, pybsgs.TABLE_LINES128_LIST, 32), (3 * (1 << 20), 3 * (1 << 18) + 1, pybsgs.TABLE_LINES64_LIST, 16)):
+        dev.build_baby_table_ext(w2, hb, layout)
+        c0 = dev.table_census()
+        assert c0["total"] == w2 and c0["malformed_lines"] == 0
+        dev.debug_corrupt_table(4 * words * 7, 1)
+        c1 = dev.table_census()
+        assert c1["total"] != c0["total"] or c1["malformed_lines"] > 0, (c0, c1)
     dev.close()
 
 

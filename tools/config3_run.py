@@ -49,6 +49,7 @@ def main():
         rec.update({"job_time_s": float(f[2].rstrip("s,")), "tiles": int(f[3]), "giant_steps": int(f[3]) * 2**25,
                     "giant_steps_per_s": int(f[3]) * 2**25 / float(f[2].rstrip("s,")), "keys_covered": int(f[3]) * 4 * 2**24 * wcount, "baby_points": wcount})
     rec["startup"] = [l for l in res.stdout.splitlines() if l.startswith("[startup]") or l.startswith("Tune for this range") or l.startswith("-w auto")]
+    rec["verification"] = [l for l in res.stdout.splitlines() if l.startswith("Table verification") or l.startswith("Replica verification")]
     chk = [l for l in res.stdout.splitlines() if l.startswith("Checker:")]
     if chk:
         rec["checker"] = chk[0]

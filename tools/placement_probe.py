@@ -9,6 +9,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "bsgs-cuda_amd"))
 import torch  # noqa: E402
+os.environ.setdefault("BSGS_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bsgs-cuda_amd", "build", "libbsgs_hip_test.so"))   # debug_realloc: test library only
 import pybsgs  # noqa: E402
 from pybsgs import ecpy  # noqa: E402
 
