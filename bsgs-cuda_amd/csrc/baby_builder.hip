@@ -45,17 +45,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     constexpr u32 WORDS = SINK == 3 ? 32u : 16u, CAP = WORDS - 1;
     const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= T) return;
-    u32 *pend_line = nullptr;          // the claim whose slot number is still in flight
-    u32 pend_slot = 0, pend_hash = 0;
-    u64 pend_bucket = 0;
+    // the claim whose slot number is still in flight: three registers (bucket, hash, slot) -- the line's address is recomputed from the bucket when the claim is
+    // settled (carrying the pointer and a 64-bit bucket cost the SINK 2 / 3 instantiations three spilled VGPRs at their 128-register budget)
+    constexpr u32 NONE = 0xFFFFFFFFu;  // never a bucket: buckets are < M < 2^32
+    u32 pend_bucket = NONE, pend_slot = 0, pend_hash = 0;
     auto settle = [&]() {
-        if (SINK == 0 || !pend_line) return;
-        if (pend_slot < CAP - 1) pend_line[1 + pend_slot] = pend_hash;             // CAP - 1 arrivals in the line; word CAP is the bound (ext_refine_kernel)
+        if (SINK == 0 || pend_bucket == NONE) return;
+        if (pend_slot < CAP - 1) K.lines[(u64)(pend_bucket - K.b_lo) * WORDS + 1 + pend_slot] = pend_hash;     // CAP - 1 arrivals in the line; word CAP is the bound (ext_refine_kernel)
         else {
             const u64 at = atomicAdd(K.counters + 16 + (u64)blockIdx.x * 16, 1ull);
-            if (at < K.region) K.ovf[(u64)blockIdx.x * K.region + at] = (pend_bucket << 32) | pend_hash;
+            if (at < K.region) K.ovf[(u64)blockIdx.x * K.region + at] = ((u64)pend_bucket << 32) | pend_hash;
         }
-        pend_line = nullptr;
+        pend_bucket = NONE;
     };
     auto emit = [&](u64 idx, u64 key) {
         if (idx >= count) return;
@@ -65,8 +66,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (bucket < K.b_lo || bucket >= K.b_hi) return;                       // another engine's slice
         pend_bucket = bucket;
         pend_hash = (u32)(key >> 32);
-        pend_line = K.lines + (u64)(bucket - K.b_lo) * WORDS;
-        pend_slot = atomicAdd(pend_line, 1u);
+        pend_slot = atomicAdd(K.lines + (u64)(bucket - K.b_lo) * WORDS, 1u);
     };
     fe Sx, Sy;
     fe_load2(Sx, bases + (u64)tid * 4 + 0, bases + (u64)tid * 4 + 1);

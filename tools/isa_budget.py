@@ -25,6 +25,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL = os.environ.get("ISA_KERNEL", "_Z18giant_pair2_kernelILi2ELb0ELb1EEv8TileArgs")
+# the translation unit that instantiates it: <2, ..> tile_lines64.hip, <3, ..> tile_lines128.hip, <4, ..> tile_lines64_any.hip (ISA_KERNEL=_Z18giant_pair2_kernelILi4ELb0ELb1EEv8TileArgs)
+TU = {"2": "tile_lines64.hip", "3": "tile_lines128.hip", "4": "tile_lines64_any.hip"}[re.search(r"kernelILi(\d)", KERNEL).group(1)]
 COST = {"mad64": 4.2, "carry": 4.1, "plain": 2.3}
 
 
@@ -40,7 +42,7 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else None
     asm = "/tmp/bsgs_isa_budget.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", *os.environ.get("ISA_DEFS", "").split(), "-S", "--cuda-device-only", "-o", asm,
-                           os.path.join(ROOT, "bsgs-cuda_amd", "csrc", "tile_lines64.hip")], stderr=subprocess.DEVNULL)
+                           os.path.join(ROOT, "bsgs-cuda_amd", "csrc", TU)], stderr=subprocess.DEVNULL)
     text = open(asm).read()
     lines = text.split("\n")
     a = next(i for i, l in enumerate(lines) if l.startswith(KERNEL + ":"))
@@ -67,7 +69,9 @@ def main():
         t = body[i].strip()
         if t and not t.startswith(";") and not t.startswith("."):
             cur["ins"].append(t.split()[0])
-    classes = collections.defaultdict(lambda: {"blocks": 0, "valu": 0, "mad64": 0, "carry": 0, "plain": 0, "s_nop": 0, "lds": 0, "vmem": 0})
+    # lane_moves = v_readlane_b32 / v_writelane_b32: what an SGPR the register allocator could not keep costs inside the loop (it parks scalars in lanes of a VGPR; the
+    # compiler remark "SGPRs Spill" counts the parked registers, this counts the instructions that move them, per class of block)
+    classes = collections.defaultdict(lambda: {"blocks": 0, "valu": 0, "mad64": 0, "carry": 0, "plain": 0, "lane_moves": 0, "s_nop": 0, "lds": 0, "vmem": 0})
     rare_tail = False
     for k, blk in enumerate(blocks):
         c = collections.Counter(blk["ins"])
@@ -99,12 +103,16 @@ def main():
         d["blocks"] += 1
         d["valu"] += valu
         d["s_nop"] += c.get("s_nop", 0)
+        d["lane_moves"] += c.get("v_readlane_b32", 0) + c.get("v_writelane_b32", 0)
         d["lds"] += sum(v for n, v in c.items() if n.startswith("ds_"))
         d["vmem"] += sum(v for n, v in c.items() if n.startswith("global_") or n.startswith("buffer_"))
         for n, v in c.items():
             if n.startswith("v_"):
                 d[group(n)] += v
-    res = {"kernel": "giant_pair2_kernel<2, false, true>" if KERNEL.endswith("ELb1EEv8TileArgs") else "giant_pair2_kernel<2, false, false>", "vgprs": int(vgpr.group(1)) if vgpr else None,
+    mode = re.search(r"kernelILi(\d)", KERNEL).group(1)
+    whole = collections.Counter(x.strip().split()[0] for x in body if x.strip() and not x.strip().startswith((";", ".")))
+    res = {"kernel": "giant_pair2_kernel<%s, false, %s>" % (mode, "true" if KERNEL.endswith("ELb1EEv8TileArgs") else "false"), "translation_unit": TU,
+           "lane_moves_whole_kernel": {"v_readlane_b32": whole.get("v_readlane_b32", 0), "v_writelane_b32": whole.get("v_writelane_b32", 0)}, "vgprs": int(vgpr.group(1)) if vgpr else None,
            "loop": "one iteration = four giants = 8 giant steps (quad chain) or one pair of giants = 4 giant steps (pair chain); two x coordinates per giant",
            "cost_cycles_per_wave_instruction": COST, "classes": {}}
     for kind, d in classes.items():
@@ -112,7 +120,7 @@ def main():
         res["classes"][kind] = d
     main_path = [res["classes"][k] for k in ("M", "S", "glue") if k in res["classes"]]
     steps_per_iteration = 8.0 if KERNEL.endswith("ELb1EEv8TileArgs") else 4.0      # quad chain: one iteration = four giants; pair chain: two
-    per_step = {g: sum(d[g] for d in main_path) / steps_per_iteration for g in ("valu", "mad64", "carry", "plain")}
+    per_step = {g: sum(d[g] for d in main_path) / steps_per_iteration for g in ("valu", "mad64", "carry", "plain", "lane_moves")}
     res["probe_loop_per_giant_step"] = {k: round(v, 1) for k, v in per_step.items()}
     res["probe_loop_per_giant_step"]["issue_cycles"] = round(sum(per_step[g] * COST[g] for g in COST), 1)
     m = res["classes"].get("M")
