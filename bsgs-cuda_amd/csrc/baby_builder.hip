@@ -35,6 +35,8 @@ struct KeySink {
     u64 region;                         // SINK 2 / 3: the overflow list is filled in one REGION of this many entries per block of the generator, each with a counter of its own
                                         // (counters[16 + 16 * block]: 128 bytes apart).  One counter for everybody held the scatter of the large tables 1.5-2.3 s above its
                                         // random-write bound: 2 * 10^9 appends at 36 * 2^30 points, every one through the same address (profiles/r08s_*)
+    u64 tail_base, tail_cap;            // SINK 2 / 3: a block whose region is full appends to the shared TAIL of the list (entries [tail_base, tail_base + tail_cap), one counter: counters[8]) --
+                                        // a region is 1/blocks of the list, and blocks that run late (a GPU that does not hold all of them at once, a single-chunk table) see fuller lines
     u32 b_lo, b_hi;                     // SINK 2 / 3: only buckets [b_lo, b_hi) are filed, in lines[(bucket - b_lo) * WORDS] (a SLICE of the table: one engine of N builds 1/N of the
                                         // lines -- every engine generates every point -- and an all-gather completes them; the whole table: 0, number of buckets)
 };
@@ -55,6 +57,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         else {
             const u64 at = atomicAdd(K.counters + 16 + (u64)blockIdx.x * 16, 1ull);
             if (at < K.region) K.ovf[(u64)blockIdx.x * K.region + at] = ((u64)pend_bucket << 32) | pend_hash;
+            else {
+                const u64 tl = atomicAdd(K.counters + 8, 1ull);               // (an entry beyond the tail is counted, not written: the host sees the count and refuses the table)
+                if (tl < K.tail_cap) K.ovf[K.tail_base + tl] = ((u64)pend_bucket << 32) | pend_hash;
+            }
         }
         pend_bucket = NONE;
     };
@@ -361,8 +367,10 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
     HIPCHK(hipMemsetAsync(lines, 0, nlines * line_bytes, d->stream));
     uint32_t gen_T = 0, gen_pi = 0;
     KeyGen::geometry(w, gen_T, gen_pi);
-    const uint64_t gen_blocks = (gen_T + 255) / 256, region = ovf_cap / gen_blocks;       // the generator's blocks (at most 1024) each fill a region of the list
-    const size_t cnt_words = 16 + gen_blocks * 16;                                          // [0] over-full lines (ext_finalize_kernel); [16 + 16 b] entries of block b's region
+    // the generator's blocks (at most 1024) each fill a region of the list; 1/32 of the list is a shared tail for the blocks whose region runs full (with equal
+    // regions alone a block that sees fuller lines than the average aborted the build although the list as a whole had room)
+    const uint64_t gen_blocks = (gen_T + 255) / 256, region = (ovf_cap - ovf_cap / 32) / gen_blocks, tail_base = region * gen_blocks, tail_cap = ovf_cap - tail_base;
+    const size_t cnt_words = 16 + gen_blocks * 16;                                          // [0] over-full lines (ext_finalize_kernel); [8] entries of the tail; [16 + 16 b] entries of block b's region
     HIPCHK(cnt.alloc(cnt_words * 8));
     HIPCHK(hipMemsetAsync(cnt.p, 0, cnt_words * 8, d->stream));
     clk.lap(d, "clear the bucket lines");
@@ -372,7 +380,7 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
         if (rc) return rc;
         KeySink K{};
         K.lines = (u32 *)lines; K.ovf = ovf; K.ovf_cap = ovf_cap; K.counters = cnt.as<unsigned long long>(); K.mask = (u32)(ht_items - 1); K.mul = ext_bucket_mul(htsz);
-        K.region = region;
+        K.region = region; K.tail_base = tail_base; K.tail_cap = tail_cap;
         if (gen.T != gen_T) return fail(BSGS_ERR_STATE, "generator geometry changed under the builder");
         K.b_lo = (u32)b_lo; K.b_hi = (u32)std::min<uint64_t>(b_hi, 0xFFFFFFFFull);
         for (uint64_t first = 1; first <= w && rc == BSGS_OK; first += gen.chunk) {
@@ -394,15 +402,21 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
     HIPCHK(hipMemcpyAsync(hc.data(), cnt.p, cnt_words * 8, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(hipStreamSynchronize(d->stream));
     h[0] = hc[0];
-    std::vector<u64> count_offset(2 * gen_blocks);
+    std::vector<u64> count_offset(2 * (gen_blocks + 1));             // the regions, then the tail as one more "region" (it starts at gen_blocks * region)
+    unsigned long long spilled = 0;
     for (uint64_t b = 0; b < gen_blocks; b++) {
-        const unsigned long long nb = hc[16 + 16 * b];
-        // (an entry beyond its region was counted, not written: the table would lack it -- never silently)
-        if (nb > region) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries in the region of generator block %llu, room for %llu (list capacity %llu)", nb, (unsigned long long)b,
-                                     (unsigned long long)region, (unsigned long long)ovf_cap);
+        const unsigned long long cb = hc[16 + 16 * b], nb = std::min<unsigned long long>(cb, region);
+        spilled += cb - nb;                                           // what block b appended beyond its region went to the tail
         count_offset[2 * b] = nb; count_offset[2 * b + 1] = h[1];
         h[1] += nb;
     }
+    // (an entry beyond the tail was counted, not written: the table would lack it -- never silently)
+    if (hc[8] != spilled) return fail(BSGS_ERR_STATE, "overflow list: %llu entries left their regions, the tail counted %llu", spilled, (unsigned long long)hc[8]);
+    if (hc[8] > tail_cap) return fail(BSGS_ERR_NOMEM, "overflow list: %llu entries beyond the regions of the generator's blocks, room for %llu in the shared tail (list capacity %llu)",
+                                      (unsigned long long)hc[8], (unsigned long long)tail_cap, (unsigned long long)ovf_cap);
+    count_offset[2 * gen_blocks] = hc[8]; count_offset[2 * gen_blocks + 1] = h[1];
+    h[1] += hc[8];
+    if (getenv("BSGS_BUILD_VERBOSE") && hc[8]) fprintf(stderr, "[build] %llu of %llu overflow entries went through the shared tail\n", (unsigned long long)hc[8], h[1]);
     clk.lap(d, "close the lines (pad, count)");
     if (h[1]) {
         // OVERFLOW BOUND (giant_kernel.hip.h): sort the overflow list by (bucket, hash), then per bucket keep the smallest hashes in the line
@@ -423,7 +437,7 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
         }
         HIPCHK(co.alloc(count_offset.size() * 8));
         HIPCHK(hipMemcpyAsync(co.p, count_offset.data(), count_offset.size() * 8, hipMemcpyHostToDevice, d->stream));
-        hipLaunchKernelGGL(ovf_compact_kernel, dim3(64, (unsigned)gen_blocks), dim3(256), 0, d->stream, (const u64 *)ovf, (u64)region, co.as<const u64>(), dense);
+        hipLaunchKernelGGL(ovf_compact_kernel, dim3(64, (unsigned)gen_blocks + 1), dim3(256), 0, d->stream, (const u64 *)ovf, (u64)region, co.as<const u64>(), dense);
         HIPCHK(hipGetLastError());
         HIPCHK(rocprim::radix_sort_keys(tmp, tmp_bytes, dense, ovf, (size_t)h[1], 0u, key_bits, d->stream));
         const int rblocks = (int)std::min<uint64_t>((h[1] + 255) / 256, 1u << 16);

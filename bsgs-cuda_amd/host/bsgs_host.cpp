@@ -137,6 +137,7 @@ int main(int argc, char **argv)
 
     // ---- recovery (-wl, 1_9_7File.pb:4634-4686)
     bool recovery = false; int rec_pos = 0; std::string rec_pub, rec_cnt;
+    std::set<int> already_won;
     if (!c.recovery_file.empty()) {
         std::ifstream f(c.recovery_file);
         std::string l1, l2, l3, l4;
@@ -144,6 +145,10 @@ int main(int argc, char **argv)
         if (!std::getline(f, l1) || !std::getline(f, l2) || !std::getline(f, l3) || !std::getline(f, l4)) die("Can`t read recovery file");
         if (strip(l4) != fingerprint(c)) die("Recovery file was made with other settings");
         rec_pos = atoi(strip(l1).c_str()); rec_pub = strip(l2); rec_cnt = strip(l3); recovery = true;
+        // list positions win.txt already reports are not searched again (with several lanes a younger job can be reported before the checkpoint names its successor)
+        std::ifstream wf(c.dir + "/win.txt", std::ios::binary);
+        std::string wl;
+        while (std::getline(wf, wl)) if (wl.rfind("KEY[", 0) == 0) already_won.insert(atoi(wl.c_str() + 4));
         printf("Recovery: listpos %d counter %s\n", rec_pos, rec_cnt.c_str());
     } else remove((c.dir + "/win.txt").c_str());                      // 1_9_7File.pb:4959-4963
 
@@ -257,6 +262,11 @@ int main(int argc, char **argv)
             {
                 std::lock_guard<std::mutex> lk(lane_mutex);
                 while (next_job < pubs.size() && recovery && (int)next_job + 1 != rec_pos) { { std::lock_guard<std::mutex> lo(out_mutex); outs[next_job].done = true; } next_job++; }      // -wl: everything before the saved position is skipped
+                while (next_job < pubs.size() && already_won.count((int)next_job + 1)) {      // ... and so is every position win.txt reports already (then the saved counter belongs to a finished job)
+                    { std::lock_guard<std::mutex> lo(out_mutex); outs[next_job].done = true; }
+                    if (recovery && (int)next_job + 1 == rec_pos) recovery = false;
+                    next_job++;
+                }
                 if (next_job >= pubs.size()) { lane_listpos[l] = 0; break; }
                 li = next_job++;
                 lane_listpos[l] = (int)li + 1;
@@ -359,6 +369,23 @@ int main(int argc, char **argv)
             say("Checker: %llu hits resolved in %.3fs of CPU time (%.2f%% of one core)\n", (unsigned long long)J.hits_checked.load(), J.checker_ns.load() * 1e-9,
                 secs > 0 ? 100.0 * J.checker_ns.load() * 1e-9 / secs : 0.0);
             { std::lock_guard<std::mutex> lk(out_mutex); o.done = true; emit(); }
+            {
+                // currentwork.txt must stop naming this job the moment it is over (the timer would let it stand for up to -wt seconds: a restart in that window searched a
+                // reported key again and appended a second KEY[n]): it now names the oldest job still in flight, or -- none in flight -- the next list position from its start
+                std::lock_guard<std::mutex> lk(lane_mutex);
+                lane_listpos[l] = 0;
+                int oldest = -1;
+                for (size_t q = 0; q < lanes; q++) if (lane_listpos[q] > 0 && (oldest < 0 || lane_listpos[q] < lane_listpos[oldest])) oldest = (int)q;
+                if (oldest >= 0) save_checkpoint(*lane_state[oldest]);
+                else if (next_job < pubs.size()) {
+                    Shared nxt;
+                    Affine q;
+                    if (hs::parse_pubkey(q, pubs[next_job]) && hs::on_curve(q)) {
+                        nxt.cfg = S.cfg; nxt.listpos = (int)next_job + 1; nxt.mainpub_hex = hs::fe_to_hex(q.x) + hs::fe_to_hex(q.y); nxt.glob_key = hs::fe_from_u64(1);
+                        save_checkpoint(nxt);
+                    }
+                }
+            }
         }
     };
     {

@@ -185,6 +185,8 @@ void save_checkpoint(Shared &S)
         for (size_t g = 0; g < S.inflight.size(); g++) if (S.inflight_valid[g] && hs::fe_cmp(S.inflight[g], cnt) < 0) cnt = S.inflight[g];
         if (S.joblog) { fprintf(S.joblog, "save %s\n", hs::fe_to_hex(cnt).c_str()); fflush(S.joblog); }
     }
+    static std::mutex file_mutex;                                   // several lanes (and a job that has just ended) may save at the same moment
+    std::lock_guard<std::mutex> fl(file_mutex);
     const std::string tmp = S.cfg.dir + "/currentwork.temp", dst = S.cfg.dir + "/currentwork.txt";
     {
         std::ofstream f(tmp, std::ios::binary);

@@ -122,6 +122,13 @@ def test_infile_sequential_and_recovery(tmp_path):
     run(geo + ["-infile", str(infile), "-pk", "1"], tmp_path)
     lines = win_lines(tmp_path)
     assert [lines[0], lines[2], lines[4]] == ["KEY[%d]: 0x%064x" % (i + 1, k) for i, k in enumerate(keys)]
+    # the checkpoint never names a finished job: when job 2 ended it was rewritten for position 3, from its start -- the timer (-wt) alone would have left
+    # position 1 or 2 standing
+    cw = (tmp_path / "currentwork.txt").read_bytes().decode().split("\r\n")
+    assert cw[0] == "3" and cw[1] == pubs[2] and int(cw[2], 16) == 1, cw
+    # a restart from that checkpoint with win.txt still in place: position 3 is reported already -> not searched again, no second KEY[3]
+    out = run(geo + ["-infile", str(infile), "-pk", "1", "-wl", str(tmp_path / "currentwork.txt")], tmp_path)
+    assert win_lines(tmp_path) == lines and "Found 0 of 3" in out
     # recovery: position 3, counter just below the tile that holds the key
     t, b, p, w, htsz = 64, 4, 8, 1 << 14, 12
     gstep = 4 * t * b * p * w
