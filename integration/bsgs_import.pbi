@@ -95,6 +95,7 @@ CompilerEndIf
   bsgs_quirk_count(dev.i, *listed)                                   ; how many giants reference-quirk mode (bsgs_set_flags 1) re-computes after every launch
   bsgs_table_census(dev.i, *out8)                                    ; round 5: the table verified like checkHT / checkHTpack (:3599-3627, :3101-3134): out(7) = entries found must equal out(6) = w, out(4) = 0
   bsgs_table_lookup(dev.i, *keys64, n.q, *found)                     ; ... and sampled membership through the shipped probe: n 64-bit keys (low 64 bits of x(k*G)) in, n bytes out
+  bsgs_sample_g2(dev.i, *idx64, n.l, *out_xy)                        ; round 6: n sampled giants as 64 bytes x_le || y_le each -- compare with (idx + 1) * ADDPUBG like checkGiantArr (:1524-1559, called :1941)
   bsgs_broadcast_tables_ex(*devs, n.l, transport.l, what.l, *transport_used, *seconds)   ; replicas with the transport chosen (0 auto, 1 RCCL over xGMI, 2 peer copies) and reported; what: 1 giants | 2 table
   bsgs_startup_ext_tables(*devs, n.l, w.q, htsz.l, layout.l, strategy.l, transport.l, *report)   ; -w above 32 on several GPUs: 0 = GPU 0 builds + broadcast, 1 = every GPU builds its own (default), 2 = 1/N each + all-gather
   bsgs_version()                                                     ; -> *ascii: the library's version line (the host's banner)
