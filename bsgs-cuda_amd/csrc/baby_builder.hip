@@ -367,9 +367,9 @@ static int ext_build_lines(bsgs_dev *d, uint64_t w, uint32_t htsz, int lplog, u3
     HIPCHK(hipMemsetAsync(lines, 0, nlines * line_bytes, d->stream));
     uint32_t gen_T = 0, gen_pi = 0;
     KeyGen::geometry(w, gen_T, gen_pi);
-    // the generator's blocks (at most 1024) each fill a region of the list; 1/32 of the list is a shared tail for the blocks whose region runs full (with equal
-    // regions alone a block that sees fuller lines than the average aborted the build although the list as a whole had room)
-    const uint64_t gen_blocks = (gen_T + 255) / 256, region = (ovf_cap - ovf_cap / 32) / gen_blocks, tail_base = region * gen_blocks, tail_cap = ovf_cap - tail_base;
+    // the generator's blocks (at most 1024) each fill a region of the list; 1/16 of the list is a shared tail for the blocks whose region runs full (with equal
+    // regions alone a block that sees fuller lines than the average aborted the build although the list as a whole had room; on a small table the blocks' shares differ by several per cent -- blocks that run late meet fuller lines)
+    const uint64_t gen_blocks = (gen_T + 255) / 256, region = (ovf_cap - ovf_cap / 16) / gen_blocks, tail_base = region * gen_blocks, tail_cap = ovf_cap - tail_base;
     const size_t cnt_words = 16 + gen_blocks * 16;                                          // [0] over-full lines (ext_finalize_kernel); [8] entries of the tail; [16 + 16 b] entries of block b's region
     HIPCHK(cnt.alloc(cnt_words * 8));
     HIPCHK(hipMemsetAsync(cnt.p, 0, cnt_words * 8, d->stream));
