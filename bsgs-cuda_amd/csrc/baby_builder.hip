@@ -140,6 +140,17 @@ __global__ void csr_items_kernel(const u64 *__restrict__ sk, const u32 *__restri
     }
 }
 
+// every point of the reference-format build left its position behind: pos[i] == i for all i < n (the array is pre-filled with 0xFFFFFFFF, never a position).  A point the
+// generator did not produce -- which the sort would file as a garbage entry among w, invisible to a census and to all but a lucky sample -- is counted here
+__global__ void __launch_bounds__(256) positions_written_kernel(const u32 *__restrict__ pos, u64 n, unsigned long long *bad)
+{
+    unsigned long long miss = 0;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) miss += pos[i] != (u32)i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) miss += __shfl_xor(miss, o);
+    if ((threadIdx.x & 63) == 0 && miss) atomicAdd(bad, miss);
+}
+
 namespace {
 // BSGS_BUILD_VERBOSE=1: stage times of the builders on stderr (wall clock; `sync` drains the stream first so that a stage owns its GPU time)
 struct StageClock {
@@ -240,6 +251,7 @@ static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img,
         if (need > fr) return fail(BSGS_ERR_NOMEM, "table build needs %.1f GiB of device memory, %.1f GiB free", need / 1073741824.0, fr / 1073741824.0);
     }
     HIPCHK(sk.alloc(w * 8)); HIPCHK(pos.alloc(w * 4));
+    HIPCHK(hipMemsetAsync(pos.p, 0xFF, w * 4, d->stream));            // "no point yet": positions_written_kernel below
     {
         KeyGen gen;
         int rc = gen.init(d, w);
@@ -254,6 +266,16 @@ static int build_to_device(bsgs_dev *d, uint64_t w, uint32_t htsz, u32 *gpu_img,
         HIPCHK(hipStreamSynchronize(d->stream));                 // the generator's scratch goes out of scope here
         rc = gen.check();
         if (rc) return rc;
+        DevBuf badb;
+        unsigned long long bad = 0;
+        HIPCHK(badb.alloc(8));
+        HIPCHK(hipMemsetAsync(badb.p, 0, 8, d->stream));
+        hipLaunchKernelGGL(positions_written_kernel, dim3((unsigned)std::min<uint64_t>((w + 255) / 256, (uint64_t)d->prop.multiProcessorCount * 16)), dim3(256), 0, d->stream,
+                           pos.as<const u32>(), (u64)w, badb.as<unsigned long long>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&bad, badb.p, 8, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        if (bad) return fail(BSGS_ERR_STATE, "table build: %llu of %llu points were not produced by the generator (their slots still hold the fill pattern)", bad, (unsigned long long)w);
         clk.lap(d, "generate the points (keys)");
     }
     // sort by (bucket, hash), positions ride along (stable: entries with an identical (bucket, hash) pair stay in ascending position order)
