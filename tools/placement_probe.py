@@ -32,8 +32,11 @@ def measure(tag, n=4):
         dev.enqueue_walk((k + 1) * tpl, tpl)
     _, _, ms = dev.collect()
     addr, gbps = dev.debug_buffers()
-    print("%-44s %7.2f ms per %d-tile launch = %.2f G/s   lines@%x chain@%x g2@%x  lines random read %.0f GB/s" % (
-        tag, ms / n, tpl, tpl * 2**25 / (ms / n * 1e-3) / 1e9, addr[0], addr[1], addr[2], gbps), flush=True)
+    cp = dev.chain_placement()
+    g = cp.get("grades_kept_first") or [0.0]
+    print("%-44s %7.2f ms per %d-tile launch = %.2f G/s   lines@%x chain@%x g2@%x  lines random read %.0f GB/s  | scratch: separation %s, kept %.1f..%.1f, all %.1f..%.1f of %d graded" % (
+        tag, ms / n, tpl, tpl * 2**25 / (ms / n * 1e-3) / 1e9, addr[0], addr[1], addr[2], gbps, cp.get("separation_seen"), cp.get("worst_kept_grade_G_per_s", 0), cp.get("best_grade_G_per_s", 0),
+        min(g), max(g), len(g)), flush=True)
 
 
 dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
@@ -103,11 +106,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "stream":
 if len(sys.argv) > 1 and sys.argv[1] == "reroll":
     # close the engine, open a new one, load everything again: does the level change inside one process?
     measure("first engine")
-    for k in range(7):
+    for k in range(int(os.environ.get("PROBE_REROLLS", "7"))):
         dev.close()
         dev = pybsgs.Device(0)
         dev.upload_htgpu_device(img.data_ptr(), items, w, 0)
         dev.generate_g2(A[0], A[1], t, b, p)
+        t0 = time.time()
+        dev.prepare()                                            # the graded allocation of the chain scratch
+        print("   prepare (chain scratch placed by grade): %.2f s" % (time.time() - t0), flush=True)
         measure("engine %d (everything re-created)" % (k + 2))
     dev.close()
     sys.exit(0)
