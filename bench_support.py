@@ -225,7 +225,7 @@ def measured_solve(timeout_s=600):
             cold = {"value": None, "note": "failed: %r" % (e,)}
         finally:
             shutil.rmtree(tmp2, ignore_errors=True)
-        # ... and the best this chip does for the same vector when the host picks the table itself (`-w auto`: Tune for the range, bsgs_host.cpp tune_plan): again an
+        # ... and the best this chip does for the same vector when the host picks the table itself (`-w auto`: Tune for the range, host_tune.cpp tune_plan): again an
         # empty directory -> key, ONE command
         best = {"value": None}
         tmp3 = tempfile.mkdtemp(prefix="bsgs_best_")

@@ -1,4 +1,4 @@
-"""GPU end-to-end tests of the C++ host (bsgs-cuda_amd/host/bsgs_host.cpp): the reference's command line,
+"""GPU end-to-end tests of the C++ host (bsgs-cuda_amd/host/): the reference's command line,
 file formats and outputs, with the reference's own known-key vectors (1_9_7File.pb:189, 191, 200-203)."""
 import hashlib
 import json

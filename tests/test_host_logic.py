@@ -1,4 +1,4 @@
-"""CPU tier: the C++ host's GPU-independent logic (bsgs-cuda_amd/host/bsgs_host.cpp -selftest) against hashlib and plain
+"""CPU tier: the C++ host's GPU-independent logic (bsgs-cuda_amd/host/host_selftest.cpp: bsgs_mi355x -selftest) against hashlib and plain
 Python integers: SHA1 / configuration fingerprint (currentwork.txt, 1_9_7File.pb:4635-4636), host EC arithmetic
 (csrc/host_secp.h), public-key parsing, the tile dispenser (GetJob, 1_9_7File.pb:2077-2092, 5046-5064) and the table-free
 resolver of the extended mode."""
